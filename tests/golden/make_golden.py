@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REFERENCE's own code.
+
+Runs ONLY in the build container (needs /root/reference).  The reference's
+scripts cannot be imported (no tensorflow/keras, hard-coded data paths --
+SURVEY.md §8c), so this script parses each file with ``ast``, pulls out the
+pure-Python/NumPy/sklearn function definitions on the hot path and executes
+exactly those definitions in a scratch namespace.  Only INPUTS and OUTPUTS are
+written to the JSON fixtures -- no reference source text is copied anywhere.
+
+Fixtures (inputs + expected outputs of the reference functions):
+  fpr_golden.json         calculate_fpr V1 (nsga_penalty.py:351-364), vectorised V1
+                          (init_sa_nsga_local.py:137-143), V3 (sa_nsga_local.py:138-141),
+                          and the y_true quirk of nsga_penalty.py:387
+  objectives_golden.json  compute_objectives_and_constraints (nsga_penalty.py:418-442,
+                          sa_nsga_penalty.py:231-253, acc_fpr_nsga_1.py:283-310) driven by a
+                          stubbed evaluate_individual; compute_model_size_mb arithmetic
+  codec_golden.json       hparams_to_vector / vector_to_hparams (mobo_penalty.py:305-338),
+                          get_lambda (nsga_penalty.py:217-219, sa_nsga_penalty.py:130-132)
+  nsga_ops_golden.json    dominates / fast_non_dominated_sort / crowding_distance
+                          (nsga_penalty.py:448-524) -- for the host-loop row N1 (next)
+"""
+import ast
+import json
+import os
+import random
+import sys
+
+import numpy as np
+from sklearn.metrics import confusion_matrix
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def extract(path, names, extra_globals=None, assigns=()):
+    """exec the named FunctionDefs (and simple top-level assignments) of one file."""
+    src = open(os.path.join(REF, path)).read()
+    tree = ast.parse(src)
+    body = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            body.append(node)
+        elif isinstance(node, ast.Assign) and len(node.targets) == 1 and \
+                isinstance(node.targets[0], ast.Name) and node.targets[0].id in assigns:
+            body.append(node)
+    found = {n.name for n in body if isinstance(n, ast.FunctionDef)}
+    missing = set(names) - found
+    if missing:
+        raise SystemExit(f"{path}: functions not found: {missing}")
+    ns = {"np": np, "confusion_matrix": confusion_matrix, "random": random, "print": lambda *a, **k: None}
+    ns.update(extra_globals or {})
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def jf(x):
+    return float(x)
+
+
+def gen_fpr():
+    v1 = extract("nsga_penalty.py", ["calculate_fpr"])["calculate_fpr"]
+    v1b = extract("ablation_study/init_sa_nsga_local.py", ["calculate_fpr"])["calculate_fpr"]
+    v3 = extract("ablation_study/sa_nsga_local.py", ["calculate_fpr"])["calculate_fpr"]
+    rs = np.random.RandomState(20250704)
+    cases = []
+
+    def add(tag, y_true, y_pred, C):
+        y_true = np.asarray(y_true, dtype=np.int64)
+        y_pred = np.asarray(y_pred, dtype=np.int64)
+        # the quirk: y_true = np.argmax(y_validation, axis=1) on an (N,1) array  (nsga_penalty.py:387)
+        yq = np.argmax(y_true[:, None], axis=1)
+        cases.append({
+            "tag": tag, "C": int(C), "y_true": y_true.tolist(), "y_pred": y_pred.tolist(),
+            "v1": jf(v1(y_true, y_pred, C)), "v1_vectorised": jf(v1b(y_true, y_pred, C)),
+            "v3": jf(v3(y_true, y_pred, C)), "v1_quirk": jf(v1(yq, y_pred, C)),
+        })
+
+    for C in (10, 11, 35):
+        for n in (1, 7, 64, 500):
+            yt = rs.randint(0, C, size=n)
+            yp = np.where(rs.rand(n) < 0.8, yt, rs.randint(0, C, size=n))
+            add(f"random_C{C}_n{n}", yt, yp, C)
+        yt = rs.randint(0, C, size=200)
+        add(f"perfect_C{C}", yt, yt, C)
+        add(f"all_pred_zero_C{C}", yt, np.zeros(200, int), C)
+        add(f"single_true_class_C{C}", np.full(50, 3), rs.randint(0, C, size=50), C)   # FP+TN==0 rows / V3 drop
+        add(f"missing_classes_C{C}", rs.randint(0, 3, size=90), rs.randint(0, 4, size=90), C)
+    add("balanced_C10", np.repeat(np.arange(10), 30), np.tile(np.arange(10), 30), 10)
+    json.dump({"source": "nsga_penalty.py:351-364; init_sa_nsga_local.py:137-143; sa_nsga_local.py:138-141; nsga_penalty.py:387",
+               "cases": cases}, open(os.path.join(OUT, "fpr_golden.json"), "w"))
+    print("fpr_golden.json", len(cases), "cases")
+
+
+def gen_objectives():
+    rs = np.random.RandomState(7)
+    out = {"cases": []}
+    scripts = [
+        ("nsga_penalty.py", dict(MIN_ACCURACY=0.9, MAX_MODEL_SIZE=2.5, MAX_FPR=0.1)),
+        ("sa_nsga_penalty.py", dict(MIN_ACCURACY=0.75, MAX_MODEL_SIZE=2.5, MAX_FPR=0.09)),
+        ("mobo_penalty.py", dict(MIN_ACCURACY=0.90, MAX_MODEL_SIZE=2.5, MAX_FPR=0.09)),
+        ("ablation_study/acc_fpr_nsga_1.py", dict(MIN_ACCURACY=0.90, MAX_MODEL_SIZE=2.5, MAX_FPR=0.09)),
+        ("ablation_study/acc_size_nsga_1.py", dict(MIN_ACCURACY=0.90, MAX_MODEL_SIZE=2.5, MAX_FPR=0.09)),
+        ("ablation_study/size_fpr_nsga_1.py", dict(MIN_ACCURACY=0.90, MAX_MODEL_SIZE=2.5, MAX_FPR=0.09)),
+    ]
+    triples = [(float(rs.uniform(0.5, 0.99)), float(rs.uniform(0.03, 6.0)), float(rs.uniform(0.0, 0.2))) for _ in range(12)]
+    triples += [(0.9, 2.5, 0.1), (0.75, 2.5, 0.09), (0.0, 51.97, 1.0)]
+    for path, thr in scripts:
+        if path == "mobo_penalty.py":
+            continue  # run_mobo inlines the assembly; thresholds recorded for the preset table only
+        calls = iter(triples)
+        ns = extract(path, ["compute_objectives_and_constraints"],
+                     dict(thr, evaluate_individual=lambda hp: next(calls)))
+        pop = [{"id": i} for i in range(len(triples))]
+        res = ns["compute_objectives_and_constraints"](pop)
+        recs = []
+        for t, r in zip(triples, res):
+            rec = {"acc": t[0], "size_mb": t[1], "fpr": t[2], "objs": [jf(v) for v in r["objs"]], "CV": jf(r["CV"])}
+            for extra in ("size_metric", "fpr_metric", "acc_metric"):
+                if extra in r:
+                    rec[extra] = jf(r[extra])
+            assert r["hparams"] is pop[len(recs)]          # the result holds a REFERENCE to the caller's dict
+            recs.append(rec)
+        out["cases"].append({"script": path, "thresholds": thr, "records": recs})
+
+    class _Stub:
+        def __init__(self, n):
+            self.n = n
+
+        def count_params(self):
+            return self.n
+    size = extract("nsga_penalty.py", ["compute_model_size_mb"])["compute_model_size_mb"]
+    counts = [19674, 20058, 20123, 21683, 324074, 13624714, 13626339, 4890634, 880106, 8106, 8298, 129418, 4915914, 1]
+    out["size_mb"] = [{"params": c, "size_mb": jf(size(_Stub(c)))} for c in counts]
+    json.dump(out, open(os.path.join(OUT, "objectives_golden.json"), "w"))
+    print("objectives_golden.json", sum(len(c["records"]) for c in out["cases"]), "records")
+
+
+def gen_codec():
+    opts = ["FILTER_OPTIONS", "KERNEL_SIZE_OPTIONS", "USE_BN_OPTIONS", "RESIDUAL_BLOCK_OPTIONS",
+            "FC_LAYER_OPTIONS", "USE_DROPOUT_OPTIONS"]
+    ns = extract("mobo_penalty.py", ["hparams_to_vector", "vector_to_hparams"], assigns=opts)
+    rs = np.random.RandomState(11)
+    enc, dec = [], []
+    for f in ns["FILTER_OPTIONS"]:
+        for k in ns["KERNEL_SIZE_OPTIONS"]:
+            for bn in ns["USE_BN_OPTIONS"]:
+                for r in ns["RESIDUAL_BLOCK_OPTIONS"]:
+                    for fc in ns["FC_LAYER_OPTIONS"]:
+                        for dr in ns["USE_DROPOUT_OPTIONS"]:
+                            hp = {"filters": f, "kernel_size": k, "use_bn": bn, "residual_blocks": r,
+                                  "fc_layers": fc, "use_dropout": dr}
+                            enc.append({"hparams": hp, "vector": [jf(v) for v in ns["hparams_to_vector"](hp)]})
+    vecs = rs.rand(64, 6).tolist() + [[0.5] * 6, [0.25] * 6, [0.75] * 6, [1 / 6.0] * 6, [0.0] * 6, [1.0] * 6]
+    for v in vecs:
+        dec.append({"vector": v, "hparams": ns["vector_to_hparams"](np.asarray(v))})
+    lam = {}
+    for path, mg in (("nsga_penalty.py", 30), ("sa_nsga_penalty.py", 30), ("sa_nsga_penalty.py", 1)):
+        g = extract(path, ["get_lambda"], dict(MAX_GEN=mg, LAMBDA_INITIAL=1.0, LAMBDA_FINAL=50.0))["get_lambda"]
+        lam[f"{path}:MAX_GEN={mg}"] = [jf(g(i)) for i in range(mg)]
+    json.dump({"encode": enc, "decode": dec, "get_lambda": lam}, open(os.path.join(OUT, "codec_golden.json"), "w"))
+    print("codec_golden.json", len(enc), "encode,", len(dec), "decode")
+
+
+def gen_nsga_ops():
+    ns = extract("nsga_penalty.py", ["dominates", "fast_non_dominated_sort", "crowding_distance"], dict(EPSILON=1e-6))
+    rs = np.random.RandomState(3)
+    cases = []
+    for n in (1, 2, 5, 15, 40):
+        for lam in (1.0, 25.5, 50.0):
+            res = [{"objs": [-float(rs.uniform(0.5, 0.99)), float(rs.choice([0.08, 0.5, 1.2, 3.0, 7.5])), float(rs.uniform(0, 0.15))],
+                    "CV": float(max(0.0, rs.uniform(-0.2, 0.3)))} for _ in range(n)]
+            fronts = ns["fast_non_dominated_sort"](res, lam)
+            crowd = [{str(k): (v if np.isfinite(v) else "inf") for k, v in ns["crowding_distance"](fr, res).items()} for fr in fronts]
+            dom = [[bool(ns["dominates"](a, b, lam)) for b in res] for a in res]
+            cases.append({"lam": lam, "results": res, "fronts": fronts, "crowding": crowd, "dominates": dom})
+    json.dump({"source": "nsga_penalty.py:448-524", "cases": cases}, open(os.path.join(OUT, "nsga_ops_golden.json"), "w"))
+    print("nsga_ops_golden.json", len(cases), "cases")
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("needs /root/reference (build container only)")
+    gen_fpr()
+    gen_objectives()
+    gen_codec()
+    gen_nsga_ops()

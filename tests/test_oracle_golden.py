@@ -1,0 +1,121 @@
+"""CPU: the oracle and the host closed forms against the reference-generated goldens.
+
+Fixtures were produced by tests/golden/make_golden.py from the reference's own
+functions (nsga_penalty.py:351-364,418-442; sa_nsga_local.py:138-141;
+mobo_penalty.py:305-338 ...).  Integer / float64 work: exact equality.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from cmoop_audio_processing_amd import genes as G
+from oracle import metrics as M
+
+
+def _load(golden_dir, name):
+    return json.load(open(os.path.join(golden_dir, name)))
+
+
+def test_fpr_variants_match_reference(golden_dir):
+    for c in _load(golden_dir, "fpr_golden.json")["cases"]:
+        yt, yp, C = c["y_true"], c["y_pred"], c["C"]
+        assert M.calculate_fpr(yt, yp, C, M.FPR_V1) == c["v1"], c["tag"]
+        assert M.calculate_fpr(yt, yp, C, M.FPR_V1) == pytest.approx(c["v1_vectorised"], abs=1e-15)
+        assert M.calculate_fpr(yt, yp, C, M.FPR_V3) == c["v3"], c["tag"]
+        assert M.calculate_fpr(yt, yp, C, M.FPR_V1_QUIRK) == c["v1_quirk"], c["tag"]
+
+
+def test_fpr_quirk_closed_form(golden_dir):
+    # with y_true == 0 everywhere FPR collapses to (1 - frac(pred==0)) / C
+    for c in _load(golden_dir, "fpr_golden.json")["cases"]:
+        yp = np.asarray(c["y_pred"])
+        assert c["v1_quirk"] == pytest.approx((1.0 - np.mean(yp == 0)) / c["C"], abs=1e-12)
+
+
+def test_objective_assembly_matches_reference(golden_dir):
+    g = _load(golden_dir, "objectives_golden.json")
+    for case in g["cases"]:
+        if not case["script"].endswith(("nsga_penalty.py", "sa_nsga_penalty.py")):
+            continue
+        t = case["thresholds"]
+        for r in case["records"]:
+            hp = {"x": 1}
+            out = M.assemble(hp, r["acc"], r["size_mb"], r["fpr"], t["MIN_ACCURACY"], t["MAX_MODEL_SIZE"], t["MAX_FPR"])
+            assert out["objs"] == r["objs"] and out["CV"] == r["CV"]
+            assert out["hparams"] is hp
+
+
+def test_size_mb_bit_exact(golden_dir):
+    for r in _load(golden_dir, "objectives_golden.json")["size_mb"]:
+        assert (r["params"] * 4) / (1024 ** 2) == r["size_mb"]
+
+
+KNOWN = [  # SURVEY.md §2.2 known-answer table: (gene, variant, classes, params)
+    ((16, 3, 0, 1, 1, 0), 0, 10, 19674), ((16, 3, 1, 1, 1, 0), 0, 10, 20058), ((16, 3, 1, 1, 1, 0), 0, 11, 20123),
+    ((16, 3, 1, 1, 1, 0), 0, 35, 21683), ((32, 3, 1, 2, 2, 0), 0, 10, 324074), ((64, 5, 1, 3, 4, 0), 0, 10, 13624714),
+    ((64, 5, 1, 3, 4, 0), 0, 35, 13626339), ((64, 3, 0, 3, 1, 0), 0, 10, 4890634), ((32, 5, 0, 2, 3, 0), 0, 10, 880106),
+    ((16, 3, 1, 1, 1, 0), 1, 10, 8298), ((16, 3, 1, 1, 1, 0), 1, 11, 8363), ((16, 3, 1, 1, 1, 0), 1, 35, 9923),
+    ((32, 3, 1, 2, 2, 0), 1, 10, 129418), ((64, 5, 1, 3, 4, 0), 1, 10, 4915914), ((64, 3, 0, 3, 1, 0), 1, 10, 1756234),
+    ((32, 5, 0, 2, 3, 0), 1, 10, 342282),
+]
+
+
+@pytest.mark.parametrize("gene,variant,classes,expect", KNOWN)
+def test_param_count_known_answers(gene, variant, classes, expect):
+    assert G.param_count(gene, variant, classes) == expect
+    assert sum(math.prod(s) for _, s, _ in G.param_tensors(gene, variant, classes)) == expect
+
+
+def test_param_count_vs_oracle_net_all_genes():
+    """Closed form == parameters the oracle's independently built topology holds
+    (all 288 genes x {A,B} x {10,11,35} classes); size_mb equal in float64."""
+    from oracle.net import OracleConfig, OracleNet
+    import oracle.rng as orng
+    real = orng.glorot_uniform
+    orng.glorot_uniform = lambda seed, ti, shape, fi, fo: np.zeros(shape, np.float32)  # skip hashing 13M weights
+    try:
+        for variant in (0, 1):
+            for classes in (10, 11, 35):
+                for g in G.all_genes():
+                    if g[5] == 1:       # dropout adds no parameters
+                        continue
+                    net = OracleNet(g, OracleConfig(variant=variant, classes=classes), 0)
+                    assert net.count_params() == G.param_count(g, variant, classes)
+                    assert net.names == [n for n, _, _ in G.param_tensors(g, variant, classes)]
+                    assert net.count_params() * 4 / 1024 ** 2 == G.model_size_mb(g, variant, classes)
+    finally:
+        orng.glorot_uniform = real
+
+
+def test_size_range_matches_survey():
+    a = [G.model_size_mb(g, 0, 10) for g in G.all_genes()]
+    b = [G.model_size_mb(g, 1, 10) for g in G.all_genes()]
+    assert min(a) == 19674 * 4 / 1024 ** 2 and max(a) == 13624714 * 4 / 1024 ** 2
+    assert min(b) == 8106 * 4 / 1024 ** 2 and max(b) == 4915914 * 4 / 1024 ** 2
+
+
+def test_gene_codec_matches_reference(golden_dir):
+    g = _load(golden_dir, "codec_golden.json")
+    for e in g["encode"]:
+        assert G.hparams_to_vector(e["hparams"]) == e["vector"]
+    for d in g["decode"]:
+        assert G.vector_to_hparams(d["vector"]) == d["hparams"]
+
+
+def test_same_pool_dims():
+    dims = [(101, 40)]
+    for _ in range(4):
+        dims.append((G.half_up(dims[-1][0]), G.half_up(dims[-1][1])))
+    assert dims == [(101, 40), (51, 20), (26, 10), (13, 5), (7, 3)]
+
+
+def test_lpt_assign_is_partition_and_balanced():
+    costs = [G.fwd_flops_per_sample(g, 0, 10, 101, 40) for g in G.all_genes()[:40]]
+    for world in (1, 2, 4, 8):
+        b = G.lpt_assign(costs, world)
+        assert sorted(i for r in b for i in r) == list(range(40))
+        loads = [sum(costs[i] for i in r) for r in b]
+        assert max(loads) <= sum(costs) / world + max(costs)
