@@ -1,0 +1,665 @@
+// HBM-bound kernels of the candidate-training path: first-layer direct conv,
+// BatchNorm (train / eval / backward), max-pool, residual add, GAP, softmax-CE,
+// Adam, confusion matrix.  All loads/stores are float4 along the channel axis of
+// NHWC tensors (coalesced 16 B/lane); every cross-thread sum has a fixed order so
+// a training run is bit-reproducible.
+#include "kernels.h"
+
+namespace cmoop {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ===========================================================================
+// first layer: C_in = 1 direct conv (Keras Conv2D(filters, k, padding='same') on
+// the (T,F,1) input, nsga_penalty.py:255 / sa_nsga_penalty.py:151)
+// ===========================================================================
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx,
+                                                        int64_t row0, const float* __restrict__ Wt,
+                                                        const float* __restrict__ bias, float* __restrict__ Y, int B,
+                                                        int H, int W, int Cout, int KS, int relu) {
+    __shared__ __attribute__((aligned(16))) float Ws[25 * 64];
+    const int t = threadIdx.x;
+    const int taps = KS * KS;
+    for (int i = t; i < taps * Cout; i += 256) {
+        int co = i / taps, tap = i - co * taps;
+        Ws[tap * Cout + co] = Wt[i];
+    }
+    __syncthreads();
+    const int TPP = Cout >> 2, PPB = 256 / TPP;
+    const int64_t pixel = (int64_t)blockIdx.x * PPB + t / TPP;
+    const int c4 = t % TPP;
+    const int HW = H * W;
+    if (pixel >= (int64_t)B * HW) return;
+    const int b = (int)(pixel / HW), r = (int)(pixel - (int64_t)b * HW);
+    const int h = r / W, w = r - h * W;
+    const int64_t src = idx ? (int64_t)idx[row0 + b] : row0 + b;
+    const float* xb = X + src * HW;
+    const int p = (KS - 1) >> 1;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
+    for (int kh = 0; kh < KS; ++kh) {
+        const int ih = h + kh - p;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        for (int kw = 0; kw < KS; ++kw) {
+            const int iw = w + kw - p;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            const float xv = xb[ih * W + iw];
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Ws[(kh * KS + kw) * Cout + 4 * c4]);
+            acc[0] = fmaf(xv, w4[0], acc[0]); acc[1] = fmaf(xv, w4[1], acc[1]);
+            acc[2] = fmaf(xv, w4[2], acc[2]); acc[3] = fmaf(xv, w4[3], acc[3]);
+        }
+    }
+    if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+    *reinterpret_cast<f32x4*>(Y + pixel * Cout + 4 * c4) = acc;
+}
+
+void launch_conv1_fwd(const float* X, const int32_t* idx, int64_t row0, const float* Wt, const float* bias, float* Y,
+                      int B, int H, int W, int Cout, int KS, int relu, hipStream_t s) {
+    CMOOP_REQUIRE(Cout % 4 == 0 && Cout <= 64 && 64 % (Cout / 4) == 0 && KS * KS <= 25, "conv1: unsupported shape");
+    const int PPB = 256 / (Cout / 4);
+    const int64_t pixels = (int64_t)B * H * W;
+    if (pixels == 0) return;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)cdiv64(pixels, PPB)), dim3(256), 0, s, X, idx, row0, Wt, bias, Y,
+                       B, H, W, Cout, KS, relu);
+    CMOOP_HIP(hipGetLastError());
+}
+
+int conv1_wgrad_blocks(int B, int H, int W) {
+    int64_t pixels = (int64_t)B * H * W;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(512, pixels / 256));
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx,
+                                                          int64_t row0, const float* __restrict__ dY,
+                                                          float* __restrict__ P, int B, int H, int W, int Cout) {
+    constexpr int TAPS = KS * KS;
+    __shared__ float red[4 * (TAPS + 1) * 64];
+    const int t = threadIdx.x;
+    const int TPP = Cout >> 2, PPB = 256 / TPP;
+    const int pl = t / TPP, c4 = t % TPP;
+    const int HW = H * W;
+    const int64_t pixels = (int64_t)B * HW;
+    constexpr int p = (KS - 1) >> 1;
+    f32x4 acc[TAPS + 1];
+#pragma unroll
+    for (int i = 0; i <= TAPS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t pixel = (int64_t)blockIdx.x * PPB + pl; pixel < pixels; pixel += (int64_t)gridDim.x * PPB) {
+        const int b = (int)(pixel / HW), r = (int)(pixel - (int64_t)b * HW);
+        const int h = r / W, w = r - h * W;
+        const int64_t src = idx ? (int64_t)idx[row0 + b] : row0 + b;
+        const float* xb = X + src * HW;
+        const f32x4 dy = *reinterpret_cast<const f32x4*>(dY + pixel * Cout + 4 * c4);
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const int ih = h + kh - p, iw = w + kw - p;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                const float xv = ok ? xb[ih * W + iw] : 0.f;
+                f32x4& a = acc[kh * KS + kw];
+                a[0] = fmaf(xv, dy[0], a[0]); a[1] = fmaf(xv, dy[1], a[1]);
+                a[2] = fmaf(xv, dy[2], a[2]); a[3] = fmaf(xv, dy[3], a[3]);
+            }
+        }
+        acc[TAPS] += dy;
+    }
+    // lanes sharing c4 sit TPP apart inside the wave: butterfly down to TPP
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int i = 0; i <= TAPS; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[i][j];
+            for (int off = 32; off >= TPP; off >>= 1) v += __shfl_xor(v, off, 64);
+            acc[i][j] = v;
+        }
+    if (lane < TPP) {
+#pragma unroll
+        for (int i = 0; i <= TAPS; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(wave * (TAPS + 1) + i) * 64 + 4 * c4 + j] = acc[i][j];
+    }
+    __syncthreads();
+    float* Pb = P + (size_t)blockIdx.x * (Cout * (TAPS + 1));
+    for (int i = t; i < (TAPS + 1) * Cout; i += 256) {
+        const int tap = i / Cout, co = i - tap * Cout;
+        float v = red[(0 * (TAPS + 1) + tap) * 64 + co] + red[(1 * (TAPS + 1) + tap) * 64 + co];
+        v += red[(2 * (TAPS + 1) + tap) * 64 + co];
+        v += red[(3 * (TAPS + 1) + tap) * 64 + co];
+        if (tap < TAPS) Pb[co * TAPS + tap] = v;        // kernel grad, canonical [co][tap]
+        else Pb[Cout * TAPS + co] = v;                  // bias grad
+    }
+}
+
+void launch_conv1_wgrad(const float* X, const int32_t* idx, int64_t row0, const float* dY, float* P, int B, int H,
+                        int W, int Cout, int KS, hipStream_t s) {
+    CMOOP_REQUIRE(Cout % 4 == 0 && Cout <= 64 && 64 % (Cout / 4) == 0, "conv1 wgrad: unsupported Cout");
+    const int nb = conv1_wgrad_blocks(B, H, W);
+    if (KS == 3) hipLaunchKernelGGL(conv1_wgrad_kernel<3>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout);
+    else if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_kernel<5>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout);
+    else CMOOP_REQUIRE(false, "conv1 wgrad: kernel size must be 3 or 5");
+    CMOOP_HIP(hipGetLastError());
+}
+
+// ===========================================================================
+// per-channel reductions over [M][C]
+// ===========================================================================
+int colreduce_blocks(int64_t M, int C) {
+    const int lanes = C / 4;
+    const int rpp = std::max(1, 256 / lanes);
+    int64_t nb = cdiv64(M, (int64_t)rpp * 16);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(1024, nb));
+}
+
+struct StatsOp {   // (sum x, sum x^2)
+    const float* X;
+    __device__ void operator()(size_t off, int, f32x4& s0, f32x4& s1) const {
+        f32x4 x = *reinterpret_cast<const f32x4*>(X + off);
+        s0 += x;
+        s1 += x * x;
+    }
+};
+struct BnBwdOp {   // (sum dy, sum dy * xhat)
+    const float* dY; const float* X; const float* mean; const float* invstd;
+    __device__ void operator()(size_t off, int c, f32x4& s0, f32x4& s1) const {
+        f32x4 dy = *reinterpret_cast<const f32x4*>(dY + off);
+        f32x4 x = *reinterpret_cast<const f32x4*>(X + off);
+        f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        s0 += dy;
+        s1 += dy * ((x - mu) * is);
+    }
+};
+
+template <class Op>
+__global__ __launch_bounds__(256) void colreduce_kernel(Op op, float* __restrict__ P, int64_t M, int C, int64_t rows_per_block) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 8];
+    const int t = threadIdx.x;
+    const int lanes = C >> 2;
+    const int rpp = 256 / lanes;
+    const int rl = t / lanes, cl = t - rl * lanes;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t rend = min(M, rbeg + rows_per_block);
+    if (rl < rpp)
+        for (int64_t r = rbeg + rl; r < rend; r += rpp) op((size_t)r * C + 4 * cl, 4 * cl, s0, s1);
+    *reinterpret_cast<f32x4*>(&red[t * 8]) = s0;
+    *reinterpret_cast<f32x4*>(&red[t * 8 + 4]) = s1;
+    __syncthreads();
+    if (rl == 0 && cl < lanes) {
+        for (int r = 1; r < rpp; ++r) {
+            s0 += *reinterpret_cast<const f32x4*>(&red[(r * lanes + cl) * 8]);
+            s1 += *reinterpret_cast<const f32x4*>(&red[(r * lanes + cl) * 8 + 4]);
+        }
+        float* Pb = P + (size_t)blockIdx.x * 2 * C;
+        *reinterpret_cast<f32x4*>(Pb + 4 * cl) = s0;
+        *reinterpret_cast<f32x4*>(Pb + C + 4 * cl) = s1;
+    }
+}
+
+static void check_colreduce(int64_t M, int C) {
+    CMOOP_REQUIRE(C % 4 == 0 && C / 4 <= 256 && C >= 4, "colreduce: C must be a multiple of 4, <= 1024");
+    (void)M;
+}
+
+void launch_colstats(const float* X, float* P, int64_t M, int C, int blocks, hipStream_t s) {
+    check_colreduce(M, C);
+    StatsOp op{X};
+    hipLaunchKernelGGL((colreduce_kernel<StatsOp>), dim3(blocks), dim3(256), 0, s, op, P, M, C, cdiv64(M, blocks));
+    CMOOP_HIP(hipGetLastError());
+}
+
+void launch_bn_bwd_reduce(const float* dY, const float* X, const float* mean, const float* invstd, float* P,
+                          int64_t M, int C, int blocks, hipStream_t s) {
+    check_colreduce(M, C);
+    BnBwdOp op{dY, X, mean, invstd};
+    hipLaunchKernelGGL((colreduce_kernel<BnBwdOp>), dim3(blocks), dim3(256), 0, s, op, P, M, C, cdiv64(M, blocks));
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ P, int blocks, int64_t M, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ mm, float* __restrict__ mv, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+                                   float eps, float momentum, float one_minus_momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+        s1 += (double)P[(size_t)b * 2 * C + c];
+        s2 += (double)P[(size_t)b * 2 * C + C + c];
+    }
+    const double mu = s1 / (double)M;
+    double var = s2 / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float muf = (float)mu, varf = (float)var;
+    const float is = (float)(1.0 / sqrt((double)varf + (double)eps));
+    const float sc = gamma[c] * is;
+    mean[c] = muf;
+    invstd[c] = is;
+    scale[c] = sc;
+    shift[c] = beta[c] - muf * sc;
+    mm[c] = mm[c] * momentum + muf * one_minus_momentum;
+    mv[c] = mv[c] * momentum + varf * one_minus_momentum;
+}
+
+void launch_bn_finalize(const float* P, int blocks, int64_t M, int C, const float* gamma, const float* beta,
+                        float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale, float* shift,
+                        float eps, float momentum, float omm, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, P, blocks, M, C, gamma, beta, moving_mean,
+                       moving_var, mean, invstd, scale, shift, eps, momentum, omm);
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ void bn_eval_prepare_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ mm, const float* __restrict__ mv,
+                                       float* __restrict__ scale, float* __restrict__ shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = (float)(1.0 / sqrt((double)mv[c] + (double)eps));
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - mm[c] * sc;
+}
+
+void launch_bn_eval_prepare(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                            float* scale, float* shift, int C, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, gamma, beta, moving_mean, moving_var,
+                       scale, shift, C, eps);
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void scale_shift_kernel(const float* __restrict__ X, float* __restrict__ Y,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int64_t n4, int C, int relu) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        f32x4 x = *reinterpret_cast<const f32x4*>(X + i * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = x[j] * sc[j] + sh[j];
+            y[j] = relu ? fmaxf(v, 0.f) : v;
+        }
+        *reinterpret_cast<f32x4*>(Y + i * 4) = y;
+    }
+}
+
+static inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 256), 8192)); }
+
+void launch_scale_shift(const float* X, float* Y, const float* scale, const float* shift, int64_t M, int C, int relu,
+                        hipStream_t s) {
+    CMOOP_REQUIRE(C % 4 == 0, "scale_shift: C % 4");
+    const int64_t n4 = M * C / 4;
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(scale_shift_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, X, Y, scale, shift, n4, C, relu);
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ P, int blocks, int C, float* __restrict__ sums,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+        s1 += (double)P[(size_t)b * 2 * C + c];
+        s2 += (double)P[(size_t)b * 2 * C + C + c];
+    }
+    sums[c] = (float)s1;
+    sums[C + c] = (float)s2;
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, float* __restrict__ dX,
+                                                           int64_t n4, int C, float invM, int mask_x_pos) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 dy = *reinterpret_cast<const f32x4*>(dY + i * 4);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(X + i * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + c);
+        const f32x4 s2 = *reinterpret_cast<const f32x4*>(sums + C + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (x[j] - mu[j]) * is[j];
+            float v = ga[j] * is[j] * (dy[j] - s1[j] * invM - xh * (s2[j] * invM));
+            if (mask_x_pos && !(x[j] > 0.f)) v = 0.f;
+            o[j] = v;
+        }
+        *reinterpret_cast<f32x4*>(dX + i * 4) = o;
+    }
+}
+
+void launch_bn_bwd_apply(const float* dY, const float* X, const float* mean, const float* invstd, const float* gamma,
+                         const float* P, int blocks, float* dX, float* dgamma, float* dbeta, int64_t M, int C,
+                         int mask_x_pos, hipStream_t s) {
+    // sums live right after the partials (caller reserves 2*C floats there)
+    float* sums = const_cast<float*>(P) + (size_t)blocks * 2 * C;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, P, blocks, C, sums, dgamma, dbeta);
+    CMOOP_HIP(hipGetLastError());
+    const int64_t n4 = M * C / 4;
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, dY, X, mean, invstd, gamma, sums, dX, n4,
+                       C, (float)(1.0 / (double)M), mask_x_pos);
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ P, int blocks, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0;
+    for (int b = 0; b < blocks; ++b) s1 += (double)P[(size_t)b * 2 * C + c];
+    out[c] = (float)s1;
+}
+
+void launch_colsum_finalize(const float* P, int blocks, int C, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, P, blocks, C, out);
+    CMOOP_HIP(hipGetLastError());
+}
+
+// tiny helpers for the output layer (C_out = classes is not a multiple of 4 / power of two)
+__global__ void colsum_small_kernel(const float* __restrict__ X, float* __restrict__ out, int M, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += X[(size_t)m * C + c];
+    out[c] = s;
+}
+
+void launch_colsum_small(const float* X, float* out, int M, int C, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, X, out, M, C);
+    CMOOP_HIP(hipGetLastError());
+}
+
+// dX[m][i] = sum_o dY[m][o] * W[o][i], optionally masked by (mask[m][i] > 0) * scale
+__global__ __launch_bounds__(256) void dense_dgrad_small_kernel(const float* __restrict__ dY, const float* __restrict__ W,
+                                                                float* __restrict__ dX, int M, int N, int K,
+                                                                const float* __restrict__ mask, float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * K) return;
+    const int m = i / K, k = i - m * K;
+    float s = 0.f;
+    for (int o = 0; o < N; ++o) s = fmaf(dY[(size_t)m * N + o], W[(size_t)o * K + k], s);
+    if (mask) s = mask[i] > 0.f ? s * scale : 0.f;
+    dX[i] = s;
+}
+
+void launch_dense_dgrad_small(const float* dY, const float* W, float* dX, int M, int N, int K, const float* mask,
+                              float scale, hipStream_t s) {
+    if (M * K == 0) return;
+    hipLaunchKernelGGL(dense_dgrad_small_kernel, dim3(cdiv(M * K, 256)), dim3(256), 0, s, dY, W, dX, M, N, K, mask, scale);
+    CMOOP_HIP(hipGetLastError());
+}
+
+// ===========================================================================
+// MaxPooling2D((2,2), strides 2, padding='same'): out = ceil(n/2), the window is
+// clipped at the bottom/right edge (TF pads with -inf).  First max wins ties.
+// ===========================================================================
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ X, float* __restrict__ Y,
+                                                          uint8_t* __restrict__ arg, int B, int H, int W, int C, int OH,
+                                                          int OW) {
+    const int C4 = C >> 2;
+    const int64_t n = (int64_t)B * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int ow = (int)(p % OW); p /= OW;
+        const int oh = (int)(p % OH);
+        const int b = (int)(p / OH);
+        f32x4 best;
+        uchar4 a = {0, 0, 0, 0};
+        bool first = true;
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            const int ih = 2 * oh + (pos >> 1), iw = 2 * ow + (pos & 1);
+            if (ih >= H || iw >= W) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(X + ((size_t)(b * H + ih) * W + iw) * C + 4 * c4);
+            if (first) { best = v; first = false; continue; }
+            if (v[0] > best[0]) { best[0] = v[0]; a.x = pos; }
+            if (v[1] > best[1]) { best[1] = v[1]; a.y = pos; }
+            if (v[2] > best[2]) { best[2] = v[2]; a.z = pos; }
+            if (v[3] > best[3]) { best[3] = v[3]; a.w = pos; }
+        }
+        *reinterpret_cast<f32x4*>(Y + i * 4) = best;
+        *reinterpret_cast<uchar4*>(arg + i * 4) = a;
+    }
+}
+
+void launch_maxpool_fwd(const float* X, float* Y, uint8_t* arg, int B, int H, int W, int C, hipStream_t s) {
+    CMOOP_REQUIRE(C % 4 == 0, "maxpool: C % 4");
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const int64_t n = (int64_t)B * OH * OW * (C / 4);
+    if (n == 0) return;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, s, X, Y, arg, B, H, W, C, OH, OW);
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ arg,
+                                                          const float* __restrict__ Y, float* __restrict__ dX, int B,
+                                                          int H, int W, int C, int OH, int OW, int mask_y_pos) {
+    const int C4 = C >> 2;
+    const int64_t n = (int64_t)B * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int ow = (int)(p % OW); p /= OW;
+        const int oh = (int)(p % OH);
+        const int b = (int)(p / OH);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dY + i * 4);
+        if (mask_y_pos) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(Y + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!(y[j] > 0.f)) g[j] = 0.f;
+        }
+        const uchar4 a = *reinterpret_cast<const uchar4*>(arg + i * 4);
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            const int ih = 2 * oh + (pos >> 1), iw = 2 * ow + (pos & 1);
+            if (ih >= H || iw >= W) continue;
+            f32x4 o;
+            o[0] = a.x == pos ? g[0] : 0.f; o[1] = a.y == pos ? g[1] : 0.f;
+            o[2] = a.z == pos ? g[2] : 0.f; o[3] = a.w == pos ? g[3] : 0.f;
+            *reinterpret_cast<f32x4*>(dX + ((size_t)(b * H + ih) * W + iw) * C + 4 * c4) = o;
+        }
+    }
+}
+
+void launch_maxpool_bwd(const float* dY, const uint8_t* arg, const float* Y, float* dX, int B, int H, int W, int C,
+                        int mask_y_pos, hipStream_t s) {
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const int64_t n = (int64_t)B * OH * OW * (C / 4);
+    if (n == 0) return;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, s, dY, arg, Y, dX, B, H, W, C, OH, OW,
+                       mask_y_pos);
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void add_relu_kernel(const float* __restrict__ A, const float* __restrict__ Bt,
+                                                       float* __restrict__ Y, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(A + i * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(Bt + i * 4);
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = fmaxf(a[j] + b[j], 0.f);
+        *reinterpret_cast<f32x4*>(Y + i * 4) = y;
+    }
+}
+
+void launch_add_relu(const float* A, const float* Bt, float* Y, int64_t n, hipStream_t s) {
+    CMOOP_REQUIRE(n % 4 == 0, "add_relu: n % 4");
+    if (n == 0) return;
+    hipLaunchKernelGGL(add_relu_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, s, A, Bt, Y, n / 4);
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ X, float* __restrict__ Y, int B, int HW,
+                                                      int C, float inv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const float* x = X + (size_t)b * HW * C + c;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += x[(size_t)p * C];
+    Y[i] = s * inv;
+}
+
+void launch_gap_fwd(const float* X, float* Y, int B, int HW, int C, hipStream_t s) {
+    if (B == 0) return;
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, s, X, Y, B, HW, C, (float)(1.0 / HW));
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                      float* __restrict__ dX, int64_t n4, int HW, int C, float inv) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i * 4;
+        const int c = (int)(e % C);
+        const int64_t b = e / ((int64_t)HW * C);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dY + b * C + c);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(X + e);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = x[j] > 0.f ? g[j] * inv : 0.f;
+        *reinterpret_cast<f32x4*>(dX + e) = o;
+    }
+}
+
+void launch_gap_bwd(const float* dY, const float* X, float* dX, int B, int HW, int C, hipStream_t s) {
+    const int64_t n4 = (int64_t)B * HW * C / 4;
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, dY, X, dX, n4, HW, C, (float)(1.0 / HW));
+    CMOOP_HIP(hipGetLastError());
+}
+
+// ===========================================================================
+// softmax + Keras-3 sparse_categorical_crossentropy(from_logits=False):
+//   p = softmax(z); pc = clip(p, 1e-7, 1-1e-7); loss = -(log pc_y - log sum_j pc_j)
+// (nsga_penalty.py:377-379 via the TF backend).  One block; rows strided over
+// threads; fixed-order LDS tree for the loss / correct counters.
+// ===========================================================================
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ Z, const int32_t* __restrict__ labels,
+                                                         const int32_t* __restrict__ idx, int64_t row0, int B, int C,
+                                                         float* __restrict__ dZ, double* __restrict__ acc,
+                                                         int32_t* __restrict__ preds) {
+    __shared__ double lsum[256];
+    __shared__ int csum[256];
+    const int t = threadIdx.x;
+    const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+    double myloss = 0.0;
+    int mycorrect = 0;
+    for (int r = t; r < B; r += 256) {
+        const float* z = Z + (size_t)r * C;
+        const int y = labels[idx ? idx[row0 + r] : row0 + r];
+        float mx = z[0];
+        int am = 0;
+        for (int j = 1; j < C; ++j)
+            if (z[j] > mx) { mx = z[j]; am = j; }
+        float se = 0.f;
+        for (int j = 0; j < C; ++j) se += expf(z[j] - mx);
+        float S = 0.f, py = 0.f, pyc = 1.f;
+        for (int j = 0; j < C; ++j) {
+            const float p = expf(z[j] - mx) / se;
+            const float pc = fminf(fmaxf(p, lo), hi);
+            S += pc;
+            if (j == y) { py = p; pyc = pc; }
+        }
+        (void)py;
+        myloss += (double)(-(logf(pyc) - logf(S)));
+        mycorrect += (am == y);
+        if (preds) preds[r] = am;
+        if (dZ) {
+            // q_j = gate_j * (1/S - [j==y]/pc_y); dz_i = p_i * (q_i - sum_j p_j q_j), then / B
+            float dot = 0.f;
+            for (int j = 0; j < C; ++j) {
+                const float p = expf(z[j] - mx) / se;
+                const float gate = (p >= lo && p <= hi) ? 1.f : 0.f;
+                const float qj = gate * (1.f / S - (j == y ? 1.f / pyc : 0.f));
+                dot += p * qj;
+            }
+            const float invB = 1.f / (float)B;
+            for (int j = 0; j < C; ++j) {
+                const float p = expf(z[j] - mx) / se;
+                const float gate = (p >= lo && p <= hi) ? 1.f : 0.f;
+                const float qj = gate * (1.f / S - (j == y ? 1.f / pyc : 0.f));
+                dZ[(size_t)r * C + j] = p * (qj - dot) * invB;
+            }
+        }
+    }
+    lsum[t] = myloss;
+    csum[t] = mycorrect;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) { lsum[t] += lsum[t + off]; csum[t] += csum[t + off]; }
+        __syncthreads();
+    }
+    if (t == 0 && acc) {
+        acc[0] += lsum[0];
+        reinterpret_cast<long long*>(acc)[1] += csum[0];
+    }
+}
+
+void launch_softmax_ce(const float* Z, const int32_t* labels, const int32_t* idx, int64_t row0, int B, int C, float* dZ,
+                       double* acc, int32_t* preds, hipStream_t s) {
+    if (B == 0) return;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, s, Z, labels, idx, row0, B, C, dZ, acc, preds);
+    CMOOP_HIP(hipGetLastError());
+}
+
+// Keras-form Adam: m += (g-m)(1-b1); v += (g^2-v)(1-b2); w -= m*alpha/(sqrt(v)+eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float alpha, float c1, float c2,
+                                                   float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        mi = mi + (gi - mi) * c1;
+        vi = vi + (gi * gi - vi) * c2;
+        m[i] = mi;
+        v[i] = vi;
+        w[i] = w[i] - (mi * alpha) / (sqrtf(vi) + eps);
+    }
+}
+
+void launch_adam(float* w, const float* g, float* m, float* v, int64_t n, float alpha, float c1, float c2, float eps,
+                 hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, s, w, g, m, v, n, alpha, c1, c2, eps);
+    CMOOP_HIP(hipGetLastError());
+}
+
+// confusion_matrix(y_true, y_pred, labels=range(C)) (nsga_penalty.py:355): LDS histogram
+__global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restrict__ yt, const int32_t* __restrict__ yp,
+                                                        int64_t n, int C, int force_true_zero, long long* __restrict__ cm) {
+    extern __shared__ int hist[];
+    for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int a = force_true_zero ? 0 : yt[i];
+        const int b = yp[i];
+        if ((unsigned)a < (unsigned)C && (unsigned)b < (unsigned)C) atomicAdd(&hist[a * C + b], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += 256) cm[i] = hist[i];
+}
+
+void launch_confusion(const int32_t* y_true, const int32_t* y_pred, int64_t n, int C, int force_true_zero, int64_t* cm,
+                      hipStream_t s) {
+    CMOOP_REQUIRE(C * C * 4 <= 64 * 1024, "confusion: too many classes");
+    hipLaunchKernelGGL(confusion_kernel, dim3(1), dim3(256), C * C * sizeof(int), s, y_true, y_pred, n, C,
+                       force_true_zero, reinterpret_cast<long long*>(cm));
+    CMOOP_HIP(hipGetLastError());
+}
+
+}  // namespace cmoop

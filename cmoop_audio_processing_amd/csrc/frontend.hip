@@ -1,0 +1,249 @@
+// Audio front end: framing -> Hann -> 512-pt FFT -> |.|^2 -> sparse Slaney mel -> log.
+// North-star addition beneath the reference's data loader (the reference ships
+// pre-extracted features only: nsga_penalty.py:64-71); the
+// algorithm restates librosa.feature.melspectrogram (requirements.txt:80) and is
+// checked against oracle/frontend.py.
+//
+// One 256-thread workgroup per clip.  The whole 1 s clip (64 KB) is read from HBM
+// once with coalesced float4 loads into LDS; the twiddle table, the window and the
+// sparse mel weights are LDS-resident too, so each clip costs 64 000 B in and
+// T*n_mels*4 B out of HBM traffic.  Each wave owns one frame at a time.
+#include "kernels.h"
+#include <cmath>
+#include <vector>
+
+namespace cmoop {
+
+struct FrontendTables {
+    FrontendCfg cfg;
+    float* tw = nullptr;       // [n_fft/2][2] cos, -sin
+    float* win = nullptr;      // [n_fft] padded periodic Hann
+    float* melw = nullptr;     // sparse weights, band after band
+    int* meloff = nullptr;     // [n_mels][2] first bin, count ; prefix offset in [2*n_mels ..]
+    int nnz = 0;
+};
+
+static double hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+static double mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+FrontendTables* frontend_tables_create(const FrontendCfg& c) {
+    CMOOP_REQUIRE(c.n_fft == 512, "front end: n_fft must be 512");
+    CMOOP_REQUIRE(c.n_mels >= 1 && c.n_mels <= 64 && c.win <= c.n_fft, "front end: n_mels <= 64, win <= n_fft");
+    auto* t = new FrontendTables;
+    t->cfg = c;
+    const int half = c.n_fft / 2, nb = half + 1;
+    std::vector<float> tw(2 * half), win(c.n_fft, 0.f);
+    for (int k = 0; k < half; ++k) {
+        const double a = -2.0 * M_PI * k / c.n_fft;
+        tw[2 * k] = (float)std::cos(a);
+        tw[2 * k + 1] = (float)std::sin(a);
+    }
+    const int lpad = (c.n_fft - c.win) / 2;
+    for (int n = 0; n < c.win; ++n) win[lpad + n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / c.win));
+    // Slaney mel basis, norm='slaney' (librosa.filters.mel)
+    std::vector<double> mel_f(c.n_mels + 2);
+    const double m_lo = hz_to_mel(c.fmin), m_hi = hz_to_mel(c.fmax);
+    for (int i = 0; i < c.n_mels + 2; ++i) mel_f[i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (c.n_mels + 1));
+    std::vector<float> w;
+    std::vector<int> off(3 * c.n_mels);
+    for (int i = 0; i < c.n_mels; ++i) {
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        int first = -1, count = 0;
+        const int start = (int)w.size();
+        for (int b = 0; b < nb; ++b) {
+            const double f = (double)b * (c.sr / 2.0) / half;
+            const double lower = (f - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+            const double upper = (mel_f[i + 2] - f) / (mel_f[i + 2] - mel_f[i + 1]);
+            const double v = std::max(0.0, std::min(lower, upper)) * enorm;
+            if (v > 0.0) {
+                if (first < 0) first = b;
+                // bins of one triangle are contiguous
+                w.push_back((float)v);
+                ++count;
+            }
+        }
+        off[2 * i] = first < 0 ? 0 : first;
+        off[2 * i + 1] = count;
+        off[2 * c.n_mels + i] = start;
+    }
+    t->nnz = (int)w.size();
+    if (w.empty()) w.push_back(0.f);
+    CMOOP_HIP(hipMalloc(&t->tw, tw.size() * 4));
+    CMOOP_HIP(hipMalloc(&t->win, win.size() * 4));
+    CMOOP_HIP(hipMalloc(&t->melw, w.size() * 4));
+    CMOOP_HIP(hipMalloc(&t->meloff, off.size() * 4));
+    CMOOP_HIP(hipMemcpy(t->tw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+    CMOOP_HIP(hipMemcpy(t->win, win.data(), win.size() * 4, hipMemcpyHostToDevice));
+    CMOOP_HIP(hipMemcpy(t->melw, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    CMOOP_HIP(hipMemcpy(t->meloff, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    CMOOP_REQUIRE(t->nnz <= 1024, "front end: mel table too large");
+    return t;
+}
+
+void frontend_tables_destroy(FrontendTables* t) {
+    if (!t) return;
+    hipFree(t->tw); hipFree(t->win); hipFree(t->melw); hipFree(t->meloff);
+    delete t;
+}
+
+constexpr int NFFT = 512, LOG2N = 9, MAXCLIP = 16384;
+
+template <bool CLIP_IN_LDS>
+__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wav, int n_samples, float* __restrict__ out,
+                                                     int T, int hop, int n_mels, float log_eps,
+                                                     const float* __restrict__ g_tw, const float* __restrict__ g_win,
+                                                     const float* __restrict__ g_melw, const int* __restrict__ g_meloff,
+                                                     int nnz) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_tw = smem;                        // 512
+    float* s_win = s_tw + NFFT;                // 512
+    float* s_melw = s_win + NFFT;              // 1024
+    float* s_re = s_melw + 1024;               // 4 * 512
+    float* s_im = s_re + 4 * NFFT;             // 4 * 512
+    int* s_off = reinterpret_cast<int*>(s_im + 4 * NFFT);   // 192
+    float* s_clip = reinterpret_cast<float*>(s_off + 192);  // n_samples (when CLIP_IN_LDS)
+
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const float* clip = wav + (size_t)blockIdx.x * n_samples;
+    for (int i = t; i < NFFT; i += 256) { s_tw[i] = g_tw[i]; s_win[i] = g_win[i]; }
+    for (int i = t; i < nnz; i += 256) s_melw[i] = g_melw[i];
+    for (int i = t; i < 3 * n_mels; i += 256) s_off[i] = g_meloff[i];
+    if (CLIP_IN_LDS) {
+        const int n4 = n_samples >> 2;
+        for (int i = t; i < n4; i += 256)
+            *reinterpret_cast<float4*>(s_clip + 4 * i) = *reinterpret_cast<const float4*>(clip + 4 * i);
+        for (int i = 4 * n4 + t; i < n_samples; i += 256) s_clip[i] = clip[i];
+    }
+    __syncthreads();
+    const float* src = CLIP_IN_LDS ? s_clip : clip;
+    float* re = s_re + wave * NFFT;
+    float* im = s_im + wave * NFFT;
+    const int iters = (T + 3) >> 2;
+    for (int it = 0; it < iters; ++it) {
+        const int frame = it * 4 + wave;
+        const bool live = frame < T;
+        // windowed frame, bit-reversed order (centre-padded with zeros: pad_mode='constant')
+        if (live) {
+            const int base = frame * hop - NFFT / 2;
+#pragma unroll
+            for (int u = 0; u < NFFT / 64; ++u) {
+                const int i = lane + 64 * u;
+                const int sidx = base + i;
+                float v = 0.f;
+                const float w = s_win[i];
+                if (w != 0.f && sidx >= 0 && sidx < n_samples) v = src[sidx] * w;
+                const int r = (int)(__brev((unsigned)i) >> (32 - LOG2N));
+                re[r] = v;
+                im[r] = 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < LOG2N; ++s) {
+            if (live) {
+                const int half = 1 << s;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = lane + 64 * u;
+                    const int pos = j & (half - 1);
+                    const int i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + half;
+                    const int k = pos << (LOG2N - 1 - s);
+                    const float wr = s_tw[2 * k], wi = s_tw[2 * k + 1];
+                    const float br = re[i1], bi = im[i1];
+                    const float tr = br * wr - bi * wi, ti = br * wi + bi * wr;
+                    const float ar = re[i0], ai = im[i0];
+                    re[i0] = ar + tr; im[i0] = ai + ti;
+                    re[i1] = ar - tr; im[i1] = ai - ti;
+                }
+            }
+            __syncthreads();
+        }
+        // power spectrum in place (bins 0..256 kept in re[])
+        if (live) {
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int b = lane + 64 * u;
+                if (b <= NFFT / 2) re[b] = re[b] * re[b] + im[b] * im[b];
+            }
+        }
+        __syncthreads();
+        if (live && lane < n_mels) {
+            const int first = s_off[2 * lane], cnt = s_off[2 * lane + 1], wo = s_off[2 * n_mels + lane];
+            float acc = 0.f;
+            for (int i = 0; i < cnt; ++i) acc = fmaf(s_melw[wo + i], re[first + i], acc);
+            out[((size_t)blockIdx.x * T + frame) * n_mels + lane] = logf(acc + log_eps);
+        }
+        __syncthreads();
+    }
+}
+
+void launch_logmel(const float* wav, int64_t n_clips, int n_samples, float* out, const FrontendTables* t, hipStream_t s) {
+    if (n_clips == 0) return;
+    const FrontendCfg& c = t->cfg;
+    const int T = 1 + n_samples / c.hop;
+    const size_t fixed = (NFFT + NFFT + 1024 + 8 * NFFT) * 4 + 192 * 4;
+    const bool in_lds = n_samples <= MAXCLIP && (n_samples % 4 == 0);
+    if (in_lds) {
+        const size_t lds = fixed + (size_t)n_samples * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            CMOOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((logmel_kernel<true>), dim3((unsigned)n_clips), dim3(256), lds, s, wav, n_samples, out, T, c.hop,
+                           c.n_mels, c.log_eps, t->tw, t->win, t->melw, t->meloff, t->nnz);
+    } else {
+        hipLaunchKernelGGL((logmel_kernel<false>), dim3((unsigned)n_clips), dim3(256), fixed, s, wav, n_samples, out, T,
+                           c.hop, c.n_mels, c.log_eps, t->tw, t->win, t->melw, t->meloff, t->nnz);
+    }
+    CMOOP_HIP(hipGetLastError());
+}
+
+// StandardScaler (nsga_penalty.py:103-141): mean / sqrt(biased var) per mel bin over N*T rows
+__global__ void colstats_f64_kernel(const float* __restrict__ P, int blocks, int64_t M, int C, double* __restrict__ mean,
+                                    double* __restrict__ scale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+        s1 += (double)P[(size_t)b * 2 * C + c];
+        s2 += (double)P[(size_t)b * 2 * C + C + c];
+    }
+    const double mu = s1 / (double)M;
+    double var = s2 / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    double sc = sqrt(var);
+    if (sc == 0.0) sc = 1.0;
+    mean[c] = mu;
+    scale[c] = sc;
+}
+
+void colstats_finalize_f64(const float* P, int blocks, int64_t M, int C, double* mean, double* scale, hipStream_t s) {
+    hipLaunchKernelGGL(colstats_f64_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, P, blocks, M, C, mean, scale);
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void standardize_kernel(float* __restrict__ X, const double* __restrict__ mean,
+                                                          const double* __restrict__ scale, int64_t n, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        X[i] = (float)(((double)X[i] - mean[c]) / scale[c]);
+    }
+}
+
+void launch_standardize(float* X, const double* mean, const double* scale, int64_t rows, int C, hipStream_t s) {
+    const int64_t n = rows * C;
+    if (n == 0) return;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 256), 16384));
+    hipLaunchKernelGGL(standardize_kernel, dim3(grid), dim3(256), 0, s, X, mean, scale, n, C);
+    CMOOP_HIP(hipGetLastError());
+}
+
+}  // namespace cmoop

@@ -1,0 +1,388 @@
+// Implicit-GEMM convolution / dense kernels on the CDNA4 fp32 matrix core
+// (v_mfma_f32_16x16x4_f32: exact f32 fmaf chain, 64 FLOP/clk/SIMD, 157 TF peak).
+//
+// Layout: activations NHWC, weights [N][K] with K = (kh, kw, ci) contiguous, so both
+// MFMA operands are staged global -> LDS as float4 along K and read back with one
+// ds_read_b128 per 16x16 tile per 16 k's: lane (row = l&15, q = l>>4) holds
+// k = 16*kk + 4*q + j for the j-th of four MFMAs (A and B use the same k assignment,
+// so the order of summation inside a 16-k group is a fixed permutation).
+#include "kernels.h"
+
+namespace cmoop {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GeomDev {
+    int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad_t, pad_l;
+    int M, K, cshift, OHW;
+};
+struct EpiDev {
+    const float* bias;
+    const float* mask;
+    float mask_scale;
+    int relu, accumulate, out_stride, OHf, OWf, dropout;
+    uint32_t drop_prefix, drop_thr;
+    float drop_scale;
+};
+
+static GeomDev to_dev(const ConvGeom& g) {
+    GeomDev d;
+    d.B = g.B; d.H = g.H; d.W = g.W; d.Cin = g.Cin; d.OH = g.OH; d.OW = g.OW; d.Cout = g.Cout;
+    d.KH = g.KH; d.KW = g.KW; d.stride = g.stride; d.pad_t = g.pad_t; d.pad_l = g.pad_l;
+    d.M = g.M(); d.K = g.K(); d.cshift = ilog2_exact(g.Cin); d.OHW = g.OH * g.OW;
+    CMOOP_REQUIRE(d.cshift >= 4, "implicit GEMM needs C_in a power of two >= 16");
+    CMOOP_REQUIRE((int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31), "input tensor too large for 32-bit indexing");
+    CMOOP_REQUIRE((int64_t)d.M * g.Cout < (1ll << 31), "output tensor too large for 32-bit indexing");
+    return d;
+}
+
+// ---------------------------------------------------------------------------
+// forward-type kernel: Y[M][N] = im2col(X)[M][K] * Wt[N][K]^T
+// block = 256 threads = 4 waves; tile 128 (M) x BN; wave w owns rows 32w..32w+31.
+// ---------------------------------------------------------------------------
+template <int BN, int BK>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                        float* __restrict__ Y, GeomDev g, EpiDev e) {
+    constexpr int BM = 128;
+    constexpr int LDK = BK + 4;
+    constexpr int TPR = BK / 4;
+    constexpr int RPP = 256 / TPR;
+    constexpr int APASS = BM / RPP;
+    constexpr int BPASS = (BN + RPP - 1) / RPP;
+    constexpr int NT = BN / 16;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+
+    const int t = threadIdx.x;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int lrow = t / TPR, kq = t % TPR;
+
+    // per-pass row decode (fixed over the K loop)
+    int a_ih0[APASS], a_iw0[APASS], a_base[APASS];
+    bool a_ok[APASS];
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+        int m = m0 + lrow + p * RPP;
+        a_ok[p] = m < g.M;
+        int mm = a_ok[p] ? m : 0;
+        int b = mm / g.OHW, r = mm - b * g.OHW;
+        int oh = r / g.OW, ow = r - oh * g.OW;
+        a_ih0[p] = oh * g.stride - g.pad_t;
+        a_iw0[p] = ow * g.stride - g.pad_l;
+        a_base[p] = b * g.H * g.W;
+    }
+
+    f32x4 ra[APASS], rb[BPASS];
+    auto load_chunk = [&](int c) {
+        const int kidx = c * BK + 4 * kq;
+        const bool kok = kidx < g.K;
+        const int tap = kidx >> g.cshift, ci = kidx & (g.Cin - 1);
+        const int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            int ih = a_ih0[p] + kh, iw = a_iw0[p] + kw;
+            bool ok = kok && a_ok[p] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(X + (((size_t)(a_base[p] + ih * g.W + iw)) << g.cshift) + ci);
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            int nl = lrow + p * RPP;
+            int n = n0 + nl;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (nl < BN && n < g.Cout && kok) v = *reinterpret_cast<const f32x4*>(Wt + (size_t)n * g.K + kidx);
+            rb[p] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < APASS; ++p)
+            *reinterpret_cast<f32x4*>(&As[buf][(lrow + p * RPP) * LDK + 4 * kq]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            int nl = lrow + p * RPP;
+            if (nl < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nl * LDK + 4 * kq]) = rb[p];
+        }
+    };
+
+    const int wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (g.K + BK - 1) / BK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            f32x4 a[2], b[NT];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                a[rt] = *reinterpret_cast<const f32x4*>(&As[buf][(wave * 32 + rt * 16 + lr) * LDK + kk * 16 + q * 4]);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+                b[ct] = *reinterpret_cast<const f32x4*>(&Bs[buf][(ct * 16 + lr) * LDK + kk * 16 + q * 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][j], b[ct][j], acc[rt][ct], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg
+    const int N = g.Cout;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wave * 32 + rt * 16 + q * 4 + r;
+            if (row >= g.M) continue;
+            size_t rbase;
+            if (e.out_stride == 1) {
+                rbase = (size_t)row * N;
+            } else {
+                int b = row / g.OHW, rr = row - b * g.OHW;
+                int oh = rr / g.OW, ow = rr - oh * g.OW;
+                rbase = ((size_t)(b * e.OHf + oh * e.out_stride) * e.OWf + ow * e.out_stride) * N;
+            }
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const int col = n0 + ct * 16 + lr;
+                if (col >= N) continue;
+                float v = acc[rt][ct][r];
+                if (e.bias) v += e.bias[col];
+                if (e.relu) v = fmaxf(v, 0.f);
+                const size_t off = rbase + col;
+                if (e.dropout) {
+                    uint32_t u24 = fmix32(e.drop_prefix ^ (uint32_t)((size_t)row * N + col)) >> 8;
+                    v = (u24 >= e.drop_thr) ? v * e.drop_scale : 0.f;
+                }
+                if (e.mask) v = (e.mask[off] > 0.f) ? v * e.mask_scale : 0.f;
+                if (e.accumulate) v += Y[off];
+                Y[off] = v;
+            }
+        }
+    }
+}
+
+template <int BN, int BK>
+static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDev& g, const EpiDev& e, hipStream_t s) {
+    dim3 grid(cdiv(g.M, 128), cdiv(g.Cout, BN));
+    hipLaunchKernelGGL((igemm_fwd_kernel<BN, BK>), grid, dim3(256), 0, s, X, Wt, Y, g, e);
+    CMOOP_HIP(hipGetLastError());
+}
+
+void launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& cg, const GemmEpilogue& ep,
+                      hipStream_t s) {
+    GeomDev g = to_dev(cg);
+    if (g.M == 0) return;
+    EpiDev e;
+    e.bias = ep.bias; e.mask = ep.mask; e.mask_scale = ep.mask_scale; e.relu = ep.relu;
+    e.accumulate = ep.accumulate; e.out_stride = ep.out_stride; e.OHf = ep.OHf; e.OWf = ep.OWf;
+    e.dropout = ep.dropout; e.drop_prefix = ep.drop_prefix; e.drop_thr = ep.drop_thr; e.drop_scale = ep.drop_scale;
+    if (e.out_stride > 1)
+        CMOOP_REQUIRE((int64_t)g.B * e.OHf * e.OWf * g.Cout < (1ll << 31), "scattered output too large");
+    const bool bk32 = (g.Cin % 32 == 0);
+    const int N = g.Cout;
+#define CMOOP_FWD(BN_)                                                        \
+    do {                                                                      \
+        if (bk32) launch_fwd_t<BN_, 32>(X, Wt, Y, g, e, s);                   \
+        else launch_fwd_t<BN_, 16>(X, Wt, Y, g, e, s);                        \
+    } while (0)
+    if (N <= 16) CMOOP_FWD(16);
+    else if (N <= 32) CMOOP_FWD(32);
+    else if (N <= 64) CMOOP_FWD(64);
+    else CMOOP_FWD(128);
+#undef CMOOP_FWD
+}
+
+// ---------------------------------------------------------------------------
+// weight-gradient kernel: dWt[N][K] = sum_m dY[m][N] * im2col(X)[m][K]
+// The MFMA reduction index is the pixel row m; both operands are read from LDS
+// m-major (ds_read_b32, leading dimension == 16 mod 32 -> conflict-free).
+// grid = (K tiles of 64, N tiles of BCO, S row-slices); partials P[S][N][K].
+// ---------------------------------------------------------------------------
+template <int BCO>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                          float* __restrict__ P, GeomDev g, int rows_per_slice) {
+    constexpr int MC = 32, BKI = 64;
+    constexpr int LDX = BKI + 16;
+    constexpr int LDY = (BCO == 16) ? 16 : BCO + 16;
+    constexpr int CT = BCO / 16;      // co tiles
+    constexpr int KPW = CT;           // k tiles per wave (4 k tiles / (4 / CT) wave groups)
+    constexpr int TPRY = BCO / 4, RPPY = 256 / TPRY;
+    constexpr int YPASS = (MC + RPPY - 1) / RPPY;
+    __shared__ __attribute__((aligned(16))) float Xs[2][MC * LDX];
+    __shared__ __attribute__((aligned(16))) float Ys[2][MC * LDY];
+
+    const int t = threadIdx.x;
+    const int k0 = blockIdx.x * BKI, co0 = blockIdx.y * BCO;
+    const int mbeg = blockIdx.z * rows_per_slice;
+    const int mend = min(g.M, mbeg + rows_per_slice);
+
+    // X gather: thread owns k index k0 + 4*(t%16) for rows t/16 and t/16 + 16
+    const int xq = t & 15, xrow = t >> 4;
+    const int kidx = k0 + 4 * xq;
+    const bool kok = kidx < g.K;
+    const int tap = kidx >> g.cshift, ci = kidx & (g.Cin - 1);
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    const int yq = t % TPRY, yrow = t / TPRY;
+    const bool cok = (co0 + 4 * yq) < g.Cout;   // Cout % 4 may be != 0: guarded per element below
+
+    f32x4 rx[2], ry[YPASS];
+    auto load_chunk = [&](int mc) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            int m = mc + xrow + p * 16;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kok && m < mend) {
+                int b = m / g.OHW, r = m - b * g.OHW;
+                int oh = r / g.OW, ow = r - oh * g.OW;
+                int ih = oh * g.stride - g.pad_t + kh, iw = ow * g.stride - g.pad_l + kw;
+                if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+                    v = *reinterpret_cast<const f32x4*>(X + (((size_t)((b * g.H + ih) * g.W + iw)) << g.cshift) + ci);
+            }
+            rx[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < YPASS; ++p) {
+            int rl = yrow + p * RPPY;
+            int m = mc + rl;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (rl < MC && m < mend && cok) {
+                const float* src = dY + (size_t)m * g.Cout + co0 + 4 * yq;
+                if (co0 + 4 * yq + 3 < g.Cout && (g.Cout & 3) == 0) {
+                    v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (co0 + 4 * yq + j < g.Cout) v[j] = src[j];
+                }
+            }
+            ry[p] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(&Xs[buf][(xrow + p * 16) * LDX + 4 * xq]) = rx[p];
+#pragma unroll
+        for (int p = 0; p < YPASS; ++p) {
+            int rl = yrow + p * RPPY;
+            if (rl < MC) *reinterpret_cast<f32x4*>(&Ys[buf][rl * LDY + 4 * yq]) = ry[p];
+        }
+    };
+
+    const int wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
+    const int co_t = wave % CT, kgrp = wave / CT;
+    f32x4 acc[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (mend > mbeg) ? (mend - mbeg + MC - 1) / MC : 0;
+    if (nchunks > 0) {
+        load_chunk(mbeg);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(mbeg + (c + 1) * MC);
+#pragma unroll
+        for (int st = 0; st < MC / 4; ++st) {
+            const float a = Ys[buf][(st * 4 + q) * LDY + co_t * 16 + lr];
+#pragma unroll
+            for (int kt = 0; kt < KPW; ++kt) {
+                const float b = Xs[buf][(st * 4 + q) * LDX + (kgrp * KPW + kt) * 16 + lr];
+                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[kt], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* Pout = P + (size_t)blockIdx.z * g.Cout * g.K;
+#pragma unroll
+    for (int kt = 0; kt < KPW; ++kt) {
+        const int kcol = k0 + (kgrp * KPW + kt) * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + co_t * 16 + q * 4 + r;
+            if (co < g.Cout && kcol < g.K) Pout[(size_t)co * g.K + kcol] = acc[kt][r];
+        }
+    }
+}
+
+int wgrad_slices(const ConvGeom& g) {
+    const int M = g.M(), K = g.K(), N = g.Cout;
+    const int bco = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+    const int tiles = cdiv(K, 64) * cdiv(N, bco);
+    int S = cdiv(2048, tiles);
+    const int maxS = std::max(1, M / 256);
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    return S;
+}
+
+void launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s) {
+    GeomDev g = to_dev(cg);
+    if (g.M == 0) return;
+    int rps = cdiv(g.M, S);
+    rps = cdiv(rps, 32) * 32;
+    const int N = g.Cout;
+    const int bco = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+    dim3 grid(cdiv(g.K, 64), cdiv(N, bco), S);
+    if (bco == 16) hipLaunchKernelGGL((igemm_wgrad_kernel<16>), grid, dim3(256), 0, s, X, dY, P, g, rps);
+    else if (bco == 32) hipLaunchKernelGGL((igemm_wgrad_kernel<32>), grid, dim3(256), 0, s, X, dY, P, g, rps);
+    else hipLaunchKernelGGL((igemm_wgrad_kernel<64>), grid, dim3(256), 0, s, X, dY, P, g, rps);
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ P, float* __restrict__ out, int S,
+                                                            int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += P[(size_t)s * n + i];
+    out[i] = acc;
+}
+
+void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, P, out, S, n);
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __restrict__ W, float* __restrict__ Wd, int Cout,
+                                                             int KH, int KW, int Cin) {
+    // thread per output element of Wd[ci][kh'][kw'][co]; co fastest -> coalesced stores
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t n = (int64_t)Cout * KH * KW * Cin;
+    if (i >= n) return;
+    int co = (int)(i % Cout);
+    int64_t r = i / Cout;
+    int kw = (int)(r % KW); r /= KW;
+    int kh = (int)(r % KH);
+    int ci = (int)(r / KH);
+    Wd[i] = W[(((size_t)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
+}
+
+void launch_flip_transpose(const float* W, float* Wd, int Cout, int KH, int KW, int Cin, hipStream_t s) {
+    int64_t n = (int64_t)Cout * KH * KW * Cin;
+    hipLaunchKernelGGL(flip_transpose_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, W, Wd, Cout, KH, KW, Cin);
+    CMOOP_HIP(hipGetLastError());
+}
+
+}  // namespace cmoop

@@ -1,0 +1,124 @@
+// Host-side launchers of every HIP kernel in libcmoop_hip.so (gfx950 / CDNA4).
+// All tensors are fp32, activations NHWC, conv/dense kernels in the canonical
+// [C_out][kh][kw][C_in] layout (K = kh*kw*C_in contiguous) -- see genes.py.
+#pragma once
+#include "common.h"
+
+namespace cmoop {
+
+// ---------------------------------------------------------------------------
+// Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_16x16x4_f32).
+// Replaces the Keras Conv2D / Dense fwd+bwd the reference delegates to TF
+// (nsga_penalty.py:255-330 via Model.fit, :383).
+// ---------------------------------------------------------------------------
+struct ConvGeom {
+    int B, H, W, Cin;        // input  [B,H,W,Cin]
+    int OH, OW, Cout;        // output [B,OH,OW,Cout]
+    int KH, KW, stride;
+    int pad_t, pad_l;        // TF "SAME": total//2 on top/left, remainder bottom/right
+    int M() const { return B * OH * OW; }
+    int K() const { return KH * KW * Cin; }
+};
+
+struct GemmEpilogue {
+    const float* bias = nullptr;   // + bias[col]
+    int relu = 0;                  // max(v, 0)
+    const float* mask = nullptr;   // v = mask[out] > 0 ? v * mask_scale : 0   (ReLU/dropout backward)
+    float mask_scale = 1.f;
+    int accumulate = 0;            // out += v
+    int out_stride = 1;            // >1: row (b,oh,ow) is stored at (b, oh*s, ow*s) of [B,OHf,OWf,N]
+    int OHf = 0, OWf = 0;
+    int dropout = 0;               // inverted dropout keyed by fmix32(drop_prefix ^ (row*N+col))
+    uint32_t drop_prefix = 0, drop_thr = 0;
+    float drop_scale = 1.f;
+};
+
+// Y[m][n] = sum_k im2col(X)[m][k] * Wt[n][k]  (+ epilogue).  Cin must be a power of two >= 16.
+void launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& g,
+                      const GemmEpilogue& e, hipStream_t s);
+
+// dWt[n][k] = sum_m dY[m][n] * im2col(X)[m][k], split over S row-slices into P[S][N][K].
+int wgrad_slices(const ConvGeom& g);
+void launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& g, int S, hipStream_t s);
+// out[i] = sum_s P[s][i]  (fixed order -> deterministic)
+void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s);
+// Wd[ci][KH-1-kh][KW-1-kw][co] = W[co][kh][kw][ci]   (operand of the dgrad implicit GEMM)
+void launch_flip_transpose(const float* W, float* Wd, int Cout, int KH, int KW, int Cin, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// First layer (C_in = 1, K = 9 or 25: too small for MFMA) -- direct conv on the VALU.
+// X is the resident feature tensor [N_total, H, W]; `idx` (may be null) gathers the
+// batch rows, fusing Keras' shuffle+batch gather (nsga_penalty.py:383) into the load.
+// ---------------------------------------------------------------------------
+void launch_conv1_fwd(const float* X, const int32_t* idx, int64_t row0, const float* Wt, const float* bias,
+                      float* Y, int B, int H, int W, int Cout, int KS, int relu, hipStream_t s);
+int conv1_wgrad_blocks(int B, int H, int W);
+// P[blk][Cout*(KS*KS) + Cout]: per-block partial kernel grads then bias grads
+void launch_conv1_wgrad(const float* X, const int32_t* idx, int64_t row0, const float* dY, float* P,
+                        int B, int H, int W, int Cout, int KS, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// Per-channel reductions over the M rows of an [M][C] tensor (C % 4 == 0).
+// Two-stage and order-fixed: `blocks` partials then a double-precision finalize.
+// ---------------------------------------------------------------------------
+int colreduce_blocks(int64_t M, int C);
+// P[blk][2][C] = (sum x, sum x^2)
+void launch_colstats(const float* X, float* P, int64_t M, int C, int blocks, hipStream_t s);
+// P[blk][2][C] = (sum dy, sum dy*xhat), xhat = (x-mean)*invstd
+void launch_bn_bwd_reduce(const float* dY, const float* X, const float* mean, const float* invstd,
+                          float* P, int64_t M, int C, int blocks, hipStream_t s);
+// BN train finalize: batch mean / biased var -> (mean, invstd, scale, shift), moving stats update
+void launch_bn_finalize(const float* P, int blocks, int64_t M, int C, const float* gamma, const float* beta,
+                        float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale,
+                        float* shift, float eps, float momentum, float one_minus_momentum, hipStream_t s);
+// BN inference: scale/shift from the moving statistics
+void launch_bn_eval_prepare(const float* gamma, const float* beta, const float* moving_mean,
+                            const float* moving_var, float* scale, float* shift, int C, float eps, hipStream_t s);
+// y = x*scale[c] + shift[c]  (optional ReLU)
+void launch_scale_shift(const float* X, float* Y, const float* scale, const float* shift, int64_t M, int C,
+                        int relu, hipStream_t s);
+// BN backward apply: dgamma/dbeta from the partials (written by block 0), then
+// dx = gamma*invstd*(dy - sum_dy/M - xhat*sum_dyxhat/M), optionally masked by (x > 0)
+void launch_bn_bwd_apply(const float* dY, const float* X, const float* mean, const float* invstd,
+                         const float* gamma, const float* P, int blocks, float* dX, float* dgamma, float* dbeta,
+                         int64_t M, int C, int mask_x_pos, hipStream_t s);
+// output layer helpers (C_out = classes: not a multiple of 4 / power of two)
+void launch_colsum_small(const float* X, float* out, int M, int C, hipStream_t s);
+void launch_dense_dgrad_small(const float* dY, const float* W, float* dX, int M, int N, int K, const float* mask,
+                              float scale, hipStream_t s);
+// out[c] = sum_blk P[blk][0][c]  (bias gradients)
+void launch_colsum_finalize(const float* P, int blocks, int C, float* out, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// Pool / residual / GAP / loss / optimiser
+// ---------------------------------------------------------------------------
+void launch_maxpool_fwd(const float* X, float* Y, uint8_t* arg, int B, int H, int W, int C, hipStream_t s);
+void launch_maxpool_bwd(const float* dY, const uint8_t* arg, const float* Y, float* dX, int B, int H, int W, int C,
+                        int mask_y_pos, hipStream_t s);
+void launch_add_relu(const float* A, const float* Bt, float* Y, int64_t n, hipStream_t s);
+void launch_gap_fwd(const float* X, float* Y, int B, int HW, int C, hipStream_t s);
+void launch_gap_bwd(const float* dY, const float* X, float* dX, int B, int HW, int C, hipStream_t s);
+// softmax + clipped sparse CE (+ gradient wrt logits when dZ != null); adds into
+// acc[0] (double: sum of per-sample losses) and acc[1] (as int64: correct); writes preds when non-null.
+void launch_softmax_ce(const float* Z, const int32_t* labels, const int32_t* idx, int64_t row0, int B, int C,
+                       float* dZ, double* acc, int32_t* preds, hipStream_t s);
+void launch_adam(float* w, const float* g, float* m, float* v, int64_t n, float alpha, float c1, float c2,
+                 float eps, hipStream_t s);
+void launch_confusion(const int32_t* y_true, const int32_t* y_pred, int64_t n, int C, int force_true_zero,
+                      int64_t* cm, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// Audio front end (north-star addition; no reference counterpart)
+// ---------------------------------------------------------------------------
+struct FrontendCfg {
+    int sr = 16000, n_fft = 512, win = 400, hop = 160, n_mels = 40;
+    float fmin = 20.f, fmax = 7600.f, log_eps = 1e-6f;
+};
+struct FrontendTables;   // device-resident twiddles / window / sparse mel weights
+FrontendTables* frontend_tables_create(const FrontendCfg& c);
+void frontend_tables_destroy(FrontendTables* t);
+void launch_logmel(const float* wav, int64_t n_clips, int n_samples, float* out, const FrontendTables* t, hipStream_t s);
+void launch_standardize(float* X, const double* mean, const double* scale, int64_t rows, int C, hipStream_t s);
+void colstats_finalize_f64(const float* P, int blocks, int64_t M, int C, double* mean, double* scale, hipStream_t s);
+
+}  // namespace cmoop

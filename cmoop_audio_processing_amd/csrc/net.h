@@ -1,0 +1,148 @@
+// One candidate CNN resident on the GPU: plan (from the six genes), parameter /
+// Adam arenas, forward, backward, optimiser step, inference.  The MI355X-native
+// replacement of build_model + model.fit/evaluate/predict
+// (/root/reference/nsga_penalty.py:225-334,375-388; sa_nsga_penalty.py:137-177,211-221).
+#pragma once
+#include "kernels.h"
+#include <atomic>
+#include <mutex>
+#include <vector>
+
+namespace cmoop {
+
+struct NetConfig {
+    int variant = 0, classes = 10, epochs = 300, batch = 64, patience = 5;
+    int early_stop = 1, restore_best = 0, acc_readout = 0, fpr_variant = 0, shuffle = 1;
+    int eval_batch = 256, n_slots = 4, profile_every = 0;
+    double lr = 1e-3, beta1 = 0.9, beta2 = 0.999, adam_eps = 1e-7, bn_eps = 1e-3, bn_momentum = 0.99, dropout = 0.3;
+};
+
+struct Dataset {
+    const float* x_train = nullptr; const int32_t* y_train = nullptr; int64_t n_train = 0;
+    const float* x_val = nullptr;   const int32_t* y_val = nullptr;   int64_t n_val = 0;
+    int T = 0, F = 0;
+};
+
+// host-side closed forms (bit-exact twins of genes.py)
+int64_t param_count(const int32_t g[6], int variant, int classes);
+double fwd_flops_per_sample(const int32_t g[6], int variant, int classes, int T, int F);
+void validate_gene(const int32_t g[6]);
+
+// HIP-event sampling of the MFMA GEMM kernels inside the timed region (bench.py roofline)
+struct ProfileTotals {
+    std::mutex mu;
+    double ms[2] = {0, 0}, flops[2] = {0, 0};
+    long long launches[2] = {0, 0};
+    void reset() { std::lock_guard<std::mutex> l(mu); ms[0] = ms[1] = flops[0] = flops[1] = 0; launches[0] = launches[1] = 0; }
+};
+ProfileTotals& profile_totals();
+
+struct GemmHook {   // brackets every MFMA GEMM launch (HIP-event sampling)
+    virtual void before(int cls, double flops) = 0;
+    virtual void after() = 0;
+    virtual ~GemmHook() {}
+};
+void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
+                           float* red_ws, hipStream_t s, GemmHook* hook);
+void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
+                        float mask_scale, int accumulate, hipStream_t s, GemmHook* hook);
+
+struct Act {
+    float* data = nullptr;
+    float* grad = nullptr;
+    int H = 0, W = 0, C = 0;
+    bool own_grad = false;
+    size_t per_sample() const { return (size_t)H * W * C; }
+};
+
+enum OpKind { OP_CONV1, OP_CONV, OP_BN, OP_POOL, OP_ADDRELU, OP_GAP, OP_DENSE };
+
+struct Op {
+    OpKind kind;
+    int in = -1, in2 = -1, out = -1;
+    // conv / dense
+    int KS = 1, stride = 1, Cin = 0, Cout = 0;
+    int relu = 0, need_dgrad = 1, in_is_relu = 0, dgrad_accumulate = 0, dropout_layer = -1;
+    float in_mask_scale = 1.f;
+    int64_t w_off = 0, b_off = 0;
+    int tensor_index = 0;   // canonical index of the kernel tensor (RNG init stream)
+    // bn
+    int64_t gamma_off = 0, beta_off = 0, mm_off = 0, mv_off = 0;
+    int relu_after = 0, mask_in_pos = 0;
+    float* bn_buf = nullptr;   // mean | invstd | scale | shift, each [C]
+    // pool
+    uint8_t* arg = nullptr;
+    int mask_y_pos = 0;
+};
+
+class Net : public GemmHook {
+  public:
+    void before(int cls, double flops) override;
+    void after() override;
+    Net(const int32_t gene[6], const NetConfig& cfg, int T, int F, uint32_t seed, hipStream_t stream);
+    ~Net();
+    Net(const Net&) = delete;
+    Net& operator=(const Net&) = delete;
+
+    int64_t total_params() const { return n_params_; }
+    void get_params(float* host);
+    void set_params(const float* host);
+    void get_grads(float* host);
+    void snapshot_params();   // device copy (restore_best_weights)
+    void restore_snapshot();
+
+    // fwd + bwd + Adam on rows idx[row0 .. row0+B) (idx may be null -> rows row0..)
+    void train_step(const float* X, const int32_t* y, const int32_t* idx, int64_t row0, int B);
+    // inference over n rows of (X, y); returns sum of per-sample losses and #correct, fills preds (device, may be null)
+    void evaluate(const float* X, const int32_t* y, int64_t n, double* loss_sum, long long* correct, int32_t* preds);
+    void read_train_metrics(double* loss_sum, long long* correct, bool reset);
+    void drain_profile();
+    hipStream_t stream() const { return stream_; }
+    long long steps_done() const { return step_; }
+
+  private:
+    void build_plan();
+    void forward(const float* X, const int32_t* idx, int64_t row0, int B, bool train);
+    void backward(const float* X, const int32_t* idx, int64_t row0, int B);
+    ConvGeom geom_of(const Op& op, int B) const;
+    void run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e);
+    float* dalloc(size_t floats);
+
+    int32_t gene_[6];
+    NetConfig cfg_;
+    int T_, F_, Bmax_;
+    uint32_t seed_;
+    hipStream_t stream_;
+    std::vector<Act> acts_;
+    std::vector<Op> ops_;
+    std::vector<void*> allocs_;
+    int64_t n_params_ = 0;
+    float *params_ = nullptr, *grads_ = nullptr, *adam_m_ = nullptr, *adam_v_ = nullptr, *snap_ = nullptr;
+    float *wgrad_ws_ = nullptr, *wd_ws_ = nullptr, *red_ws_ = nullptr;
+    size_t wgrad_ws_floats_ = 0, wd_ws_floats_ = 0, red_ws_floats_ = 0;
+    double* acc_train_ = nullptr;   // [2]: loss sum, correct (int64 bits)
+    double* acc_eval_ = nullptr;
+    int logits_ = -1;
+    long long step_ = 0, iterations_ = 0;
+    bool profiling_now_ = false, hook_live_ = false;
+    struct EvPair { hipEvent_t a, b; double flops; int cls; };
+    std::vector<EvPair> ev_pool_;
+    size_t ev_used_ = 0;
+};
+
+struct EvalResult {
+    double acc = 0, size_mb = 0, fpr = 0, val_loss = 0, seconds = 0;
+    int epochs_run = 0;
+};
+
+// train-to-early-stop + readouts for one candidate (evaluate_individual, nsga_penalty.py:368-395)
+EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Dataset& ds, uint32_t seed, hipStream_t stream);
+// the population loop (compute_objectives_and_constraints, nsga_penalty.py:418-442): n_slots
+// candidates in flight on their own HIP streams, longest-first
+void eval_population(const NetConfig& cfg, const Dataset& ds, const int32_t* genes, const uint32_t* seeds, int n,
+                     EvalResult* out);
+
+double fpr_from_confusion(const int64_t* cm, int C, int variant);
+void epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out);
+
+}  // namespace cmoop

@@ -1,0 +1,688 @@
+// Candidate network: plan, training step, inference, early-stopped fit and the
+// population driver.  See net.h for the reference lines each piece replaces.
+#include "net.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <thread>
+
+namespace cmoop {
+
+static const int FC_LADDER[5][4] = {{0, 0, 0, 0}, {64, 0, 0, 0}, {128, 64, 0, 0}, {256, 128, 64, 0}, {512, 256, 128, 64}};
+
+void validate_gene(const int32_t g[6]) {
+    const bool ok = (g[0] == 16 || g[0] == 32 || g[0] == 64) && (g[1] == 3 || g[1] == 5) && (g[2] == 0 || g[2] == 1) &&
+                    (g[3] >= 1 && g[3] <= 3) && (g[4] >= 1 && g[4] <= 4) && (g[5] == 0 || g[5] == 1);
+    CMOOP_REQUIRE(ok, "gene outside the search space (filters{16,32,64}, kernel{3,5}, bn{0,1}, res{1..3}, fc{1..4}, dropout{0,1})");
+}
+
+int64_t param_count(const int32_t g[6], int variant, int classes) {
+    validate_gene(g);
+    const int64_t f = g[0], kk = (int64_t)g[1] * g[1], bn = g[2], R = g[3], fc = g[4];
+    int64_t p, c = f;
+    if (variant == 0) {
+        p = (kk * f + f) + (kk * f * f + f) + (bn ? 8 * f : 0);
+        for (int r = 0; r < R; ++r) {
+            p += c * 2 * c + 2 * c;
+            p += kk * c * 2 * c + 2 * c;
+            p += kk * (2 * c) * (2 * c) + 2 * c;
+            p += bn ? 16 * c : 0;
+            c *= 2;
+        }
+    } else {
+        p = (kk * f + f) + (bn ? 4 * f : 0);
+        for (int r = 0; r < R; ++r) {
+            p += c * 2 * c + 2 * c;
+            p += kk * c * 2 * c + 2 * c;
+            p += bn ? 8 * c : 0;
+            c *= 2;
+        }
+    }
+    int64_t prev = c;
+    for (int i = 0; i < fc; ++i) {
+        const int64_t u = FC_LADDER[fc][i];
+        p += prev * u + u;
+        prev = u;
+    }
+    p += prev * classes + classes;
+    return p;
+}
+
+double fwd_flops_per_sample(const int32_t g[6], int variant, int classes, int T, int F) {
+    validate_gene(g);
+    const double f = g[0], kk = (double)g[1] * g[1];
+    const int R = g[3], fc = g[4];
+    double fl = 2.0 * T * F * kk * f;
+    if (variant == 0) fl += 2.0 * T * F * kk * f * f;
+    int h = (T + 1) / 2, w = (F + 1) / 2;
+    double c = f;
+    for (int r = 0; r < R; ++r) {
+        const int h2 = (h + 1) / 2, w2 = (w + 1) / 2;
+        fl += 2.0 * h2 * w2 * c * 2 * c;
+        fl += 2.0 * h * w * kk * c * 2 * c;
+        if (variant == 0) fl += 2.0 * h * w * kk * 2 * c * 2 * c;
+        h = h2; w = w2; c *= 2;
+    }
+    double prev = c;
+    for (int i = 0; i < fc; ++i) {
+        fl += 2.0 * prev * FC_LADDER[fc][i];
+        prev = FC_LADDER[fc][i];
+    }
+    fl += 2.0 * prev * classes;
+    return fl;
+}
+
+ProfileTotals& profile_totals() {
+    static ProfileTotals t;
+    return t;
+}
+
+// ---------------------------------------------------------------------------
+float* Net::dalloc(size_t floats) {
+    void* p = nullptr;
+    CMOOP_HIP(hipMalloc(&p, std::max<size_t>(floats, 4) * sizeof(float)));
+    allocs_.push_back(p);
+    return static_cast<float*>(p);
+}
+
+Net::Net(const int32_t gene[6], const NetConfig& cfg, int T, int F, uint32_t seed, hipStream_t stream)
+    : cfg_(cfg), T_(T), F_(F), seed_(seed), stream_(stream) {
+    validate_gene(gene);
+    CMOOP_REQUIRE(cfg.classes >= 2 && cfg.classes <= 64, "classes must be in [2, 64]");
+    CMOOP_REQUIRE(cfg.batch >= 1 && cfg.batch <= 4096 && cfg.eval_batch >= 1, "bad batch size");
+    CMOOP_REQUIRE(T >= 1 && F >= 1, "bad feature shape");
+    std::memcpy(gene_, gene, sizeof(gene_));
+    Bmax_ = std::max(cfg.batch, cfg.eval_batch);
+    build_plan();
+}
+
+Net::~Net() {
+    for (auto& e : ev_pool_) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (void* p : allocs_) hipFree(p);
+}
+
+void Net::build_plan() {
+    const int f = gene_[0], k = gene_[1], bn = gene_[2], R = gene_[3], fc = gene_[4], dr = gene_[5];
+    const bool A = cfg_.variant == 0;
+    int64_t off = 0;
+    int tindex = 0;
+
+    auto new_act = [&](int H, int W, int C) {
+        Act a; a.H = H; a.W = W; a.C = C;
+        acts_.push_back(a);
+        return (int)acts_.size() - 1;
+    };
+    new_act(T_, F_, 1);   // 0: the input features (never materialised: conv1 reads the resident tensor)
+
+    auto add_conv = [&](OpKind kind, int in, int Cout, int KS, int stride, int relu, int in_is_relu, float mask_scale,
+                        int accumulate) {
+        Op op; op.kind = kind; op.in = in;
+        const Act& ia = acts_[in];
+        op.KS = KS; op.stride = stride; op.Cin = ia.C; op.Cout = Cout; op.relu = relu;
+        op.in_is_relu = in_is_relu; op.in_mask_scale = mask_scale; op.dgrad_accumulate = accumulate;
+        op.w_off = off; op.tensor_index = tindex;
+        off += (int64_t)Cout * KS * KS * ia.C;
+        op.b_off = off; off += Cout;
+        tindex += 2;
+        op.out = new_act((ia.H + stride - 1) / stride, (ia.W + stride - 1) / stride, Cout);
+        ops_.push_back(op);
+        return op.out;
+    };
+    auto add_bn = [&](int in, int relu_after, int mask_in_pos) {
+        Op op; op.kind = OP_BN; op.in = in; op.relu_after = relu_after; op.mask_in_pos = mask_in_pos;
+        const Act ia = acts_[in];
+        op.Cout = ia.C;
+        op.gamma_off = off; off += ia.C;
+        op.beta_off = off; off += ia.C;
+        op.mm_off = off; off += ia.C;
+        op.mv_off = off; off += ia.C;
+        tindex += 4;
+        op.out = new_act(ia.H, ia.W, ia.C);
+        ops_.push_back(op);
+        return op.out;
+    };
+    auto add_pool = [&](int in, int mask_y_pos) {
+        Op op; op.kind = OP_POOL; op.in = in; op.mask_y_pos = mask_y_pos;
+        const Act ia = acts_[in];
+        op.out = new_act((ia.H + 1) / 2, (ia.W + 1) / 2, ia.C);
+        ops_.push_back(op);
+        return op.out;
+    };
+
+    int x;
+    if (A) {   // nsga_penalty.py:255-265
+        x = add_conv(OP_CONV1, 0, f, k, 1, !bn, 0, 1.f, 0);
+        if (bn) x = add_bn(x, 1, 0);
+        x = add_conv(OP_CONV, x, f, k, 1, !bn, 1, 1.f, 0);
+        if (bn) x = add_bn(x, 1, 0);
+        x = add_pool(x, 0);
+    } else {   // sa_nsga_penalty.py:151-153 (ReLU fused into the conv, BN after it)
+        x = add_conv(OP_CONV1, 0, f, k, 1, 1, 0, 1.f, 0);
+        if (bn) x = add_bn(x, 0, 1);
+        x = add_pool(x, !bn);
+    }
+    int c = f;
+    for (int r = 0; r < R; ++r) {
+        // the block input is a ReLU output (so consumers mask their dgrad by x > 0), except
+        // topology B's first block, whose input is pool(BN(.)) or pool(relu(.)) handled in the pool
+        const int in_relu = (A || r > 0) ? 1 : 0;
+        const int skip = add_conv(OP_CONV, x, 2 * c, 1, 2, 0, in_relu, 1.f, 1);
+        int y;
+        if (A) {   // nsga_penalty.py:276-301
+            y = add_conv(OP_CONV, x, 2 * c, k, 1, !bn, in_relu, 1.f, 0);
+            if (bn) y = add_bn(y, 1, 0);
+            y = add_conv(OP_CONV, y, 2 * c, k, 1, 0, 1, 1.f, 0);
+            if (bn) y = add_bn(y, 0, 0);
+            y = add_pool(y, 0);
+        } else {   // sa_nsga_penalty.py:155-165
+            y = add_conv(OP_CONV, x, 2 * c, k, 1, 1, in_relu, 1.f, 0);
+            if (bn) y = add_bn(y, 0, 1);
+            y = add_pool(y, !bn);
+        }
+        Op op; op.kind = OP_ADDRELU; op.in = y; op.in2 = skip;
+        op.out = new_act(acts_[y].H, acts_[y].W, acts_[y].C);
+        ops_.push_back(op);
+        x = op.out;
+        c *= 2;
+    }
+    {
+        Op op; op.kind = OP_GAP; op.in = x;
+        op.out = new_act(1, 1, acts_[x].C);
+        ops_.push_back(op);
+        x = op.out;
+    }
+    const float keep_scale = (float)(1.0 / (1.0 - cfg_.dropout));
+    for (int i = 0; i < fc; ++i) {
+        const int in_relu = i > 0;
+        const float ms = (in_relu && dr) ? keep_scale : 1.f;
+        x = add_conv(OP_DENSE, x, FC_LADDER[fc][i], 1, 1, 1, in_relu, ms, 0);
+        if (dr) ops_.back().dropout_layer = i;
+    }
+    x = add_conv(OP_DENSE, x, cfg_.classes, 1, 1, 0, 1, dr ? keep_scale : 1.f, 0);
+    logits_ = x;
+    n_params_ = off;
+    CMOOP_REQUIRE(n_params_ == param_count(gene_, cfg_.variant, cfg_.classes), "plan / closed-form parameter count mismatch");
+
+    // ---- activations ------------------------------------------------------
+    for (size_t i = 1; i < acts_.size(); ++i) acts_[i].data = dalloc((size_t)Bmax_ * acts_[i].per_sample());
+    // gradients: residual add aliases its operands' grads with its output's
+    for (size_t i = 1; i < acts_.size(); ++i) {
+        acts_[i].grad = dalloc((size_t)cfg_.batch * acts_[i].per_sample());
+        acts_[i].own_grad = true;
+    }
+    for (auto& op : ops_)
+        if (op.kind == OP_ADDRELU) {
+            acts_[op.in].grad = acts_[op.out].grad;
+            acts_[op.in2].grad = acts_[op.out].grad;
+        }
+    // ---- parameters / optimiser state ---------------------------------------
+    params_ = dalloc(n_params_); grads_ = dalloc(n_params_);
+    adam_m_ = dalloc(n_params_); adam_v_ = dalloc(n_params_);
+    CMOOP_HIP(hipMemsetAsync(grads_, 0, n_params_ * 4, stream_));
+    CMOOP_HIP(hipMemsetAsync(adam_m_, 0, n_params_ * 4, stream_));
+    CMOOP_HIP(hipMemsetAsync(adam_v_, 0, n_params_ * 4, stream_));
+    std::vector<float> host(n_params_, 0.f);
+    for (const auto& op : ops_) {
+        if (op.kind == OP_BN) {
+            for (int i = 0; i < op.Cout; ++i) { host[op.gamma_off + i] = 1.f; host[op.mv_off + i] = 1.f; }
+        } else if (op.kind == OP_CONV1 || op.kind == OP_CONV || op.kind == OP_DENSE) {
+            // glorot_uniform: limit = sqrt(6 / (fan_in + fan_out)), fan = k*k*C  (oracle/rng.py twin)
+            const double fan_in = (double)op.KS * op.KS * op.Cin, fan_out = (double)op.KS * op.KS * op.Cout;
+            const double limit = std::sqrt(6.0 / (fan_in + fan_out));
+            const float scale = (float)(limit / 16777216.0);
+            const int64_t n = (int64_t)op.Cout * op.KS * op.KS * op.Cin;
+            const uint32_t prefix = rng_prefix(seed_, STREAM_INIT + (uint32_t)op.tensor_index, 0);
+            for (int64_t i = 0; i < n; ++i) {
+                const int64_t u24 = fmix32(prefix ^ (uint32_t)i) >> 8;
+                host[op.w_off + i] = (float)(2 * u24 - 16777216) * scale;
+            }
+        }
+    }
+    CMOOP_HIP(hipMemcpyAsync(params_, host.data(), n_params_ * 4, hipMemcpyHostToDevice, stream_));
+    CMOOP_HIP(hipStreamSynchronize(stream_));
+
+    // ---- per-op buffers and shared workspaces --------------------------------
+    for (auto& op : ops_) {
+        if (op.kind == OP_BN) op.bn_buf = dalloc(4 * (size_t)op.Cout);
+        if (op.kind == OP_POOL) {
+            void* p = nullptr;
+            CMOOP_HIP(hipMalloc(&p, (size_t)Bmax_ * acts_[op.out].per_sample()));
+            allocs_.push_back(p);
+            op.arg = static_cast<uint8_t*>(p);
+        }
+        if (op.kind == OP_CONV || op.kind == OP_DENSE) {
+            const ConvGeom g = geom_of(op, cfg_.batch);
+            wgrad_ws_floats_ = std::max(wgrad_ws_floats_, (size_t)wgrad_slices(g) * g.Cout * g.K());
+            wd_ws_floats_ = std::max(wd_ws_floats_, (size_t)g.Cout * g.K());
+            const int64_t M = g.M();
+            if (op.Cout % 4 == 0)
+                red_ws_floats_ = std::max(red_ws_floats_, (size_t)colreduce_blocks(M, op.Cout) * 2 * op.Cout + 2 * op.Cout);
+        }
+        if (op.kind == OP_CONV1) {
+            const size_t per = (size_t)op.Cout * (op.KS * op.KS + 1);
+            wgrad_ws_floats_ = std::max(wgrad_ws_floats_, per * conv1_wgrad_blocks(cfg_.batch, T_, F_));
+            red_ws_floats_ = std::max(red_ws_floats_, (size_t)colreduce_blocks((int64_t)Bmax_ * T_ * F_, op.Cout) * 2 * op.Cout + 2 * op.Cout);
+        }
+        if (op.kind == OP_BN) {
+            const int64_t M = (int64_t)Bmax_ * acts_[op.in].H * acts_[op.in].W;
+            red_ws_floats_ = std::max(red_ws_floats_, (size_t)colreduce_blocks(M, op.Cout) * 2 * op.Cout + 2 * op.Cout);
+        }
+    }
+    wgrad_ws_ = dalloc(wgrad_ws_floats_);
+    wd_ws_ = dalloc(wd_ws_floats_);
+    red_ws_ = dalloc(red_ws_floats_ + 64);
+    acc_train_ = reinterpret_cast<double*>(dalloc(8));
+    acc_eval_ = acc_train_ + 2;
+    CMOOP_HIP(hipMemsetAsync(acc_train_, 0, 32, stream_));
+    if (cfg_.profile_every > 0) {
+        ev_pool_.resize(1024);
+        for (auto& e : ev_pool_) { CMOOP_HIP(hipEventCreate(&e.a)); CMOOP_HIP(hipEventCreate(&e.b)); }
+    }
+}
+
+ConvGeom Net::geom_of(const Op& op, int B) const {
+    const Act& ia = acts_[op.in];
+    ConvGeom g;
+    g.B = B; g.H = ia.H; g.W = ia.W; g.Cin = op.Cin;
+    g.OH = (ia.H + op.stride - 1) / op.stride; g.OW = (ia.W + op.stride - 1) / op.stride; g.Cout = op.Cout;
+    g.KH = g.KW = op.KS; g.stride = op.stride;
+    const int th = std::max((g.OH - 1) * op.stride + op.KS - ia.H, 0);
+    const int tw = std::max((g.OW - 1) * op.stride + op.KS - ia.W, 0);
+    g.pad_t = th / 2; g.pad_l = tw / 2;
+    return g;
+}
+
+void Net::get_params(float* host) {
+    CMOOP_HIP(hipMemcpyAsync(host, params_, n_params_ * 4, hipMemcpyDeviceToHost, stream_));
+    CMOOP_HIP(hipStreamSynchronize(stream_));
+}
+void Net::set_params(const float* host) {
+    CMOOP_HIP(hipMemcpyAsync(params_, host, n_params_ * 4, hipMemcpyHostToDevice, stream_));
+    CMOOP_HIP(hipStreamSynchronize(stream_));
+}
+void Net::get_grads(float* host) {
+    CMOOP_HIP(hipMemcpyAsync(host, grads_, n_params_ * 4, hipMemcpyDeviceToHost, stream_));
+    CMOOP_HIP(hipStreamSynchronize(stream_));
+}
+void Net::snapshot_params() {
+    if (!snap_) snap_ = dalloc(n_params_);
+    CMOOP_HIP(hipMemcpyAsync(snap_, params_, n_params_ * 4, hipMemcpyDeviceToDevice, stream_));
+}
+void Net::restore_snapshot() {
+    if (snap_) CMOOP_HIP(hipMemcpyAsync(params_, snap_, n_params_ * 4, hipMemcpyDeviceToDevice, stream_));
+}
+
+void Net::before(int cls, double flops) {
+    hook_live_ = profiling_now_ && ev_used_ < ev_pool_.size();
+    if (!hook_live_) return;
+    CMOOP_HIP(hipEventRecord(ev_pool_[ev_used_].a, stream_));
+    ev_pool_[ev_used_].flops = flops;
+    ev_pool_[ev_used_].cls = cls;
+}
+void Net::after() {
+    if (!hook_live_) return;
+    CMOOP_HIP(hipEventRecord(ev_pool_[ev_used_].b, stream_));
+    ++ev_used_;
+    hook_live_ = false;
+}
+
+// dW[N][K] and db[N] of a conv / dense layer: MFMA split over row slices, then a fixed-order slice sum
+void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
+                           float* red_ws, hipStream_t s, GemmHook* hook) {
+    const int M = g.M(), N = g.Cout, K = g.K();
+    const int S = wgrad_slices(g);
+    if (hook) hook->before(1, 2.0 * M * (double)N * K);
+    launch_igemm_wgrad(X, dY, wgrad_ws, g, S, s);
+    if (hook) hook->after();
+    launch_reduce_slices(wgrad_ws, dW, S, (int64_t)N * K, s);
+    if (N % 4 == 0) {
+        const int nb = colreduce_blocks(M, N);
+        launch_colstats(dY, red_ws, M, N, nb, s);
+        launch_colsum_finalize(red_ws, nb, N, dB, s);
+    } else {
+        launch_colsum_small(dY, dB, M, N, s);
+    }
+}
+
+// dX of a conv / dense layer: the same implicit-GEMM kernel on dY with flip-transposed weights.
+// `g` is the FORWARD geometry.  mask != null applies the ReLU (and dropout scale) backward of the
+// layer's input in the epilogue; accumulate adds into dX (second consumer of a tensor).
+void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
+                        float mask_scale, int accumulate, hipStream_t s, GemmHook* hook) {
+    const int N = g.Cout;
+    if (ilog2_exact(N) < 4) {   // output layer: K_dgrad = classes (10/11/35) -- tiny VALU kernel
+        CMOOP_REQUIRE(g.KH == 1 && g.H == 1 && g.W == 1 && !accumulate, "non power-of-two C_out only supported for dense layers");
+        launch_dense_dgrad_small(dY, W, dX, g.M(), N, g.K(), mask, mask_scale, s);
+        return;
+    }
+    launch_flip_transpose(W, wd_ws, N, g.KH, g.KW, g.Cin, s);
+    ConvGeom gd;
+    GemmEpilogue e;
+    gd.B = g.B; gd.H = g.OH; gd.W = g.OW; gd.Cin = N; gd.Cout = g.Cin; gd.stride = 1;
+    if (g.stride == 1) {
+        gd.OH = g.H; gd.OW = g.W; gd.KH = g.KH; gd.KW = g.KW;
+        gd.pad_t = g.KH - 1 - g.pad_t; gd.pad_l = g.KW - 1 - g.pad_l;
+    } else {
+        CMOOP_REQUIRE(g.KH == 1 && g.KW == 1 && accumulate, "strided conv dgrad: only the 1x1 skip projection (accumulating)");
+        gd.OH = g.OH; gd.OW = g.OW; gd.KH = gd.KW = 1; gd.pad_t = gd.pad_l = 0;
+        e.out_stride = g.stride; e.OHf = g.H; e.OWf = g.W;
+    }
+    e.accumulate = accumulate;
+    e.mask = mask;
+    e.mask_scale = mask_scale;
+    if (hook) hook->before(0, 2.0 * gd.M() * (double)gd.Cout * gd.K());
+    launch_igemm_fwd(dY, wd_ws, dX, gd, e, s);
+    if (hook) hook->after();
+}
+
+void Net::run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e) {
+    before(cls, 2.0 * g.M() * (double)g.Cout * g.K());
+    launch_igemm_fwd(X, Wt, Y, g, e, stream_);
+    after();
+}
+
+void Net::drain_profile() {
+    if (!ev_used_) return;
+    ProfileTotals& t = profile_totals();
+    std::lock_guard<std::mutex> l(t.mu);
+    for (size_t i = 0; i < ev_used_; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b) == hipSuccess) {
+            t.ms[ev_pool_[i].cls] += ms;
+            t.flops[ev_pool_[i].cls] += ev_pool_[i].flops;
+            t.launches[ev_pool_[i].cls] += 1;
+        }
+    }
+    ev_used_ = 0;
+}
+
+// ---------------------------------------------------------------------------
+void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool train) {
+    CMOOP_REQUIRE(B >= 1 && B <= Bmax_, "batch larger than the net was planned for");
+    for (const Op& op : ops_) {
+        switch (op.kind) {
+        case OP_CONV1:
+            launch_conv1_fwd(X, idx, row0, params_ + op.w_off, params_ + op.b_off, acts_[op.out].data, B, T_, F_, op.Cout,
+                             op.KS, op.relu, stream_);
+            break;
+        case OP_CONV:
+        case OP_DENSE: {
+            GemmEpilogue e;
+            e.bias = params_ + op.b_off;
+            e.relu = op.relu;
+            if (train && op.dropout_layer >= 0) {
+                e.dropout = 1;
+                e.drop_prefix = rng_prefix(seed_, STREAM_DROPOUT + (uint32_t)op.dropout_layer, (uint32_t)step_);
+                e.drop_thr = (uint32_t)(cfg_.dropout * 16777216.0);
+                e.drop_scale = (float)(1.0 / (1.0 - cfg_.dropout));
+            }
+            run_gemm(0, acts_[op.in].data, params_ + op.w_off, acts_[op.out].data, geom_of(op, B), e);
+            break;
+        }
+        case OP_BN: {
+            const Act& ia = acts_[op.in];
+            const int64_t M = (int64_t)B * ia.H * ia.W;
+            const int C = op.Cout;
+            float *mean = op.bn_buf, *invstd = mean + C, *scale = invstd + C, *shift = scale + C;
+            if (train) {
+                const int nb = colreduce_blocks(M, C);
+                launch_colstats(ia.data, red_ws_, M, C, nb, stream_);
+                launch_bn_finalize(red_ws_, nb, M, C, params_ + op.gamma_off, params_ + op.beta_off, params_ + op.mm_off,
+                                   params_ + op.mv_off, mean, invstd, scale, shift, (float)cfg_.bn_eps, (float)cfg_.bn_momentum,
+                                   (float)(1.0 - cfg_.bn_momentum), stream_);
+            } else {
+                launch_bn_eval_prepare(params_ + op.gamma_off, params_ + op.beta_off, params_ + op.mm_off,
+                                       params_ + op.mv_off, scale, shift, C, (float)cfg_.bn_eps, stream_);
+            }
+            launch_scale_shift(ia.data, acts_[op.out].data, scale, shift, M, C, op.relu_after, stream_);
+            break;
+        }
+        case OP_POOL: {
+            const Act& ia = acts_[op.in];
+            launch_maxpool_fwd(ia.data, acts_[op.out].data, op.arg, B, ia.H, ia.W, ia.C, stream_);
+            break;
+        }
+        case OP_ADDRELU:
+            launch_add_relu(acts_[op.in].data, acts_[op.in2].data, acts_[op.out].data,
+                            (int64_t)B * acts_[op.out].per_sample(), stream_);
+            break;
+        case OP_GAP: {
+            const Act& ia = acts_[op.in];
+            launch_gap_fwd(ia.data, acts_[op.out].data, B, ia.H * ia.W, ia.C, stream_);
+            break;
+        }
+        }
+    }
+}
+
+void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B) {
+    for (int oi = (int)ops_.size() - 1; oi >= 0; --oi) {
+        const Op& op = ops_[oi];
+        switch (op.kind) {
+        case OP_CONV:
+        case OP_DENSE: {
+            const ConvGeom g = geom_of(op, B);
+            const float* dY = acts_[op.out].grad;
+            Act& ia = acts_[op.in];
+            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, red_ws_, stream_, this);
+            if (op.need_dgrad)
+                conv_backward_data(dY, params_ + op.w_off, ia.grad, g, wd_ws_, op.in_is_relu ? ia.data : nullptr,
+                                   op.in_mask_scale, op.dgrad_accumulate, stream_, this);
+            break;
+        }
+        case OP_BN: {
+            const Act& ia = acts_[op.in];
+            const int64_t M = (int64_t)B * ia.H * ia.W;
+            const int C = op.Cout;
+            float *mean = op.bn_buf, *invstd = mean + C;
+            const int nb = colreduce_blocks(M, C);
+            launch_bn_bwd_reduce(acts_[op.out].grad, ia.data, mean, invstd, red_ws_, M, C, nb, stream_);
+            launch_bn_bwd_apply(acts_[op.out].grad, ia.data, mean, invstd, params_ + op.gamma_off, red_ws_, nb, ia.grad,
+                                grads_ + op.gamma_off, grads_ + op.beta_off, M, C, op.mask_in_pos, stream_);
+            break;
+        }
+        case OP_POOL: {
+            const Act& ia = acts_[op.in];
+            launch_maxpool_bwd(acts_[op.out].grad, op.arg, acts_[op.out].data, ia.grad, B, ia.H, ia.W, ia.C, op.mask_y_pos,
+                               stream_);
+            break;
+        }
+        case OP_ADDRELU:
+            break;   // operands alias the output gradient (consumers already applied the ReLU mask)
+        case OP_GAP: {
+            const Act& ia = acts_[op.in];
+            launch_gap_bwd(acts_[op.out].grad, ia.data, ia.grad, B, ia.H * ia.W, ia.C, stream_);
+            break;
+        }
+        case OP_CONV1: {
+            launch_conv1_wgrad(X, idx, row0, acts_[op.out].grad, wgrad_ws_, B, T_, F_, op.Cout, op.KS, stream_);
+            launch_reduce_slices(wgrad_ws_, grads_ + op.w_off, conv1_wgrad_blocks(B, T_, F_),
+                                 (int64_t)op.Cout * (op.KS * op.KS + 1), stream_);
+            break;
+        }
+        }
+    }
+}
+
+void Net::train_step(const float* X, const int32_t* y, const int32_t* idx, int64_t row0, int B) {
+    CMOOP_REQUIRE(B >= 1 && B <= cfg_.batch, "train batch larger than configured");
+    profiling_now_ = cfg_.profile_every > 0 && (step_ % cfg_.profile_every) == 0;
+    forward(X, idx, row0, B, true);
+    launch_softmax_ce(acts_[logits_].data, y, idx, row0, B, cfg_.classes, acts_[logits_].grad, acc_train_, nullptr, stream_);
+    backward(X, idx, row0, B);
+    ++iterations_;
+    const double t = (double)iterations_;
+    const double b1 = cfg_.beta1, b2 = cfg_.beta2;
+    const float alpha = (float)(cfg_.lr * std::sqrt(1.0 - std::pow(b2, t)) / (1.0 - std::pow(b1, t)));
+    launch_adam(params_, grads_, adam_m_, adam_v_, n_params_, alpha, (float)(1.0 - b1), (float)(1.0 - b2),
+                (float)cfg_.adam_eps, stream_);
+    ++step_;
+    profiling_now_ = false;
+}
+
+void Net::evaluate(const float* X, const int32_t* y, int64_t n, double* loss_sum, long long* correct, int32_t* preds) {
+    CMOOP_HIP(hipMemsetAsync(acc_eval_, 0, 16, stream_));
+    for (int64_t s = 0; s < n; s += cfg_.eval_batch) {
+        const int B = (int)std::min<int64_t>(cfg_.eval_batch, n - s);
+        forward(X, nullptr, s, B, false);
+        launch_softmax_ce(acts_[logits_].data, y, nullptr, s, B, cfg_.classes, nullptr, acc_eval_, preds ? preds + s : nullptr,
+                          stream_);
+    }
+    double host[2];
+    CMOOP_HIP(hipMemcpyAsync(host, acc_eval_, 16, hipMemcpyDeviceToHost, stream_));
+    CMOOP_HIP(hipStreamSynchronize(stream_));
+    *loss_sum = host[0];
+    std::memcpy(correct, &host[1], 8);
+}
+
+void Net::read_train_metrics(double* loss_sum, long long* correct, bool reset) {
+    double host[2];
+    CMOOP_HIP(hipMemcpyAsync(host, acc_train_, 16, hipMemcpyDeviceToHost, stream_));
+    if (reset) CMOOP_HIP(hipMemsetAsync(acc_train_, 0, 16, stream_));
+    CMOOP_HIP(hipStreamSynchronize(stream_));
+    *loss_sum = host[0];
+    std::memcpy(correct, &host[1], 8);
+}
+
+// ---------------------------------------------------------------------------
+void epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out) {
+    std::vector<uint64_t> key(n);
+    const uint32_t prefix = rng_prefix(seed, STREAM_SHUFFLE, epoch);
+    for (int64_t i = 0; i < n; ++i) key[i] = ((uint64_t)fmix32(prefix ^ (uint32_t)i) << 32) | (uint64_t)i;
+    std::sort(key.begin(), key.end());
+    for (int64_t i = 0; i < n; ++i) out[i] = (int32_t)(key[i] & 0xFFFFFFFFull);
+}
+
+double fpr_from_confusion(const int64_t* cm, int C, int variant) {
+    // calculate_fpr: V1 nsga_penalty.py:351-364 ; V3 ablation_study/sa_nsga_local.py:138-141
+    long long total = 0;
+    std::vector<long long> row(C, 0), col(C, 0);
+    for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) { total += cm[i * C + j]; row[i] += cm[i * C + j]; col[j] += cm[i * C + j]; }
+    double sum = 0.0;
+    int cnt = 0;
+    for (int i = 0; i < C; ++i) {
+        const long long fp = col[i] - cm[i * C + i];
+        if (variant == 2) {
+            const long long den = total - row[i];
+            if (den > 0) { sum += (double)fp / (double)den; ++cnt; }
+        } else {
+            const long long tn = total - (row[i] + col[i] - cm[i * C + i]);
+            sum += (fp + tn) > 0 ? (double)fp / (double)(fp + tn) : 0.0;
+            ++cnt;
+        }
+    }
+    // np.mean sums left to right in float64 for such short lists (pairwise kicks in at 128 elements)
+    return cnt ? sum / cnt : 0.0;
+}
+
+EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Dataset& ds, uint32_t seed, hipStream_t stream) {
+    const auto t0 = std::chrono::steady_clock::now();
+    CMOOP_REQUIRE(ds.n_train >= 1 && ds.n_val >= 1, "empty train or validation split");
+    CMOOP_REQUIRE(ds.n_train < (1ll << 31) && ds.n_val < (1ll << 31), "split too large");
+    Net net(gene, cfg, ds.T, ds.F, seed, stream);
+    EvalResult res;
+    res.size_mb = (double)(net.total_params() * 4) / (1024.0 * 1024.0);   // compute_model_size_mb, nsga_penalty.py:337-344
+
+    int32_t* h_idx = nullptr;
+    int32_t* d_idx = nullptr;
+    int32_t* d_preds = nullptr;
+    int64_t* d_cm = nullptr;
+    CMOOP_HIP(hipHostMalloc(&h_idx, ds.n_train * 4));
+    CMOOP_HIP(hipMalloc(&d_idx, ds.n_train * 4));
+    CMOOP_HIP(hipMalloc(&d_preds, ds.n_val * 4));
+    CMOOP_HIP(hipMalloc(&d_cm, (size_t)cfg.classes * cfg.classes * 8));
+    auto cleanup = [&]() { hipHostFree(h_idx); hipFree(d_idx); hipFree(d_preds); hipFree(d_cm); };
+    try {
+        // Model.fit + EarlyStopping(monitor='val_loss', patience) -- keras/src/callbacks/early_stopping.py (3.6)
+        double best = INFINITY, last_val_acc = 0.0, last_val_loss = 0.0;
+        int wait = 0;
+        bool have_best = false;
+        for (int epoch = 0; epoch < cfg.epochs; ++epoch) {
+            if (cfg.shuffle) epoch_permutation(seed, (uint32_t)epoch, ds.n_train, h_idx);
+            else std::iota(h_idx, h_idx + ds.n_train, 0);
+            CMOOP_HIP(hipMemcpyAsync(d_idx, h_idx, ds.n_train * 4, hipMemcpyHostToDevice, stream));
+            for (int64_t s = 0; s < ds.n_train; s += cfg.batch)
+                net.train_step(ds.x_train, ds.y_train, d_idx, s, (int)std::min<int64_t>(cfg.batch, ds.n_train - s));
+            double ls; long long corr;
+            net.evaluate(ds.x_val, ds.y_val, ds.n_val, &ls, &corr, nullptr);
+            net.drain_profile();
+            last_val_loss = ls / (double)ds.n_val;
+            last_val_acc = (double)corr / (double)ds.n_val;
+            res.epochs_run = epoch + 1;
+            if (!cfg.early_stop) continue;
+            if (cfg.restore_best && !have_best) { net.snapshot_params(); have_best = true; }
+            ++wait;
+            if (last_val_loss < best) {
+                best = last_val_loss;
+                if (cfg.restore_best) net.snapshot_params();
+                wait = 0;
+                continue;
+            }
+            if (wait >= cfg.patience && epoch > 0) break;
+        }
+        if (cfg.early_stop && cfg.restore_best && have_best) net.restore_snapshot();
+        // readouts: model.evaluate / model.predict + argmax + confusion matrix (one pass yields both)
+        double ls; long long corr;
+        net.evaluate(ds.x_val, ds.y_val, ds.n_val, &ls, &corr, d_preds);
+        res.val_loss = cfg.acc_readout == 0 ? last_val_loss : ls / (double)ds.n_val;
+        res.acc = cfg.acc_readout == 0 ? last_val_acc : (double)corr / (double)ds.n_val;
+        launch_confusion(ds.y_val, d_preds, ds.n_val, cfg.classes, cfg.fpr_variant == 1, d_cm, stream);
+        std::vector<int64_t> cm((size_t)cfg.classes * cfg.classes);
+        CMOOP_HIP(hipMemcpyAsync(cm.data(), d_cm, cm.size() * 8, hipMemcpyDeviceToHost, stream));
+        CMOOP_HIP(hipStreamSynchronize(stream));
+        res.fpr = fpr_from_confusion(cm.data(), cfg.classes, cfg.fpr_variant == 2 ? 2 : 0);
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+    res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return res;
+}
+
+void eval_population(const NetConfig& cfg, const Dataset& ds, const int32_t* genes, const uint32_t* seeds, int n,
+                     EvalResult* out) {
+    if (n <= 0) return;
+    for (int i = 0; i < n; ++i) validate_gene(genes + 6 * i);
+    // longest first (closed-form FLOPs) so the tail of the generation is made of cheap candidates
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::vector<double> cost(n);
+    for (int i = 0; i < n; ++i) cost[i] = fwd_flops_per_sample(genes + 6 * i, cfg.variant, cfg.classes, ds.T, ds.F);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    int dev = 0;
+    CMOOP_HIP(hipGetDevice(&dev));
+    const int slots = std::max(1, std::min(cfg.n_slots, n));
+    std::atomic<int> next{0};
+    std::mutex err_mu;
+    std::string err;
+    auto worker = [&]() {
+        hipStream_t stream = nullptr;
+        try {
+            CMOOP_HIP(hipSetDevice(dev));
+            CMOOP_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            for (;;) {
+                const int j = next.fetch_add(1);
+                if (j >= n) break;
+                { std::lock_guard<std::mutex> l(err_mu); if (!err.empty()) break; }
+                const int i = order[j];
+                out[i] = run_candidate(genes + 6 * i, cfg, ds, seeds[i], stream);
+            }
+        } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> l(err_mu);
+            if (err.empty()) err = e.what();
+        }
+        if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
+    };
+    std::vector<std::thread> th;
+    for (int s = 1; s < slots; ++s) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+    if (!err.empty()) throw Error(err);
+}
+
+}  // namespace cmoop

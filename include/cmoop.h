@@ -1,0 +1,137 @@
+/* cmoop.h -- C ABI of libcmoop_hip.so: the MI355X-native population-fitness evaluator.
+ *
+ * This is the drop-in boundary for ONE path of sumansamui/CMOOP_Audio_Processing:
+ *     compute_objectives_and_constraints(population) -> evaluate_individual(hparams)
+ *       -> build_model / compile / fit / evaluate / predict / calculate_fpr / compute_model_size_mb
+ * (reference nsga_penalty.py:225-442, sa_nsga_penalty.py:137-253 and their copies in
+ * mobo_penalty.py and ablation_study/).  The reference is pure Python over TensorFlow;
+ * it has no FFI of its own, so the functions below are what a ctypes binding of that
+ * path binds (INTEGRATION.md shows the stub).  Plain pointers and sizes only: device
+ * buffers are raw HIP device pointers (e.g. torch.Tensor.data_ptr()), no torch types.
+ *
+ * Every function returns 0 on success, non-zero on failure; cmoop_last_error() returns
+ * the message of the calling thread's last failure.  The reference's own error
+ * convention is "any exception kills the run" (no try/except around
+ * nsga_penalty.py:383); the Python shim re-raises these codes as RuntimeError.
+ */
+#ifndef CMOOP_H
+#define CMOOP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMOOP_ABI_VERSION 1
+
+/* topologies hidden behind the reference's build_model(hparams) */
+#define CMOOP_VARIANT_A 0 /* "deep":    nsga_penalty.py:225-334, mobo_penalty.py:128-194 */
+#define CMOOP_VARIANT_B 1 /* "shallow": sa_nsga_penalty.py:137-177 and the sa_/psi_/init_ ablations */
+
+/* calculate_fpr variants */
+#define CMOOP_FPR_V1 0       /* nsga_penalty.py:351-364 (= sa_nsga_penalty.py:189-202) */
+#define CMOOP_FPR_V1_QUIRK 1 /* V1 with y_true = argmax of an (N,1) array == zeros, nsga_penalty.py:387 */
+#define CMOOP_FPR_V3 2       /* ablation_study/sa_nsga_local.py:138-141 */
+
+/* Evaluation protocol: the module-level constants the reference's evaluate_individual
+ * closes over (nsga_penalty.py:176-179) plus the Keras defaults it relies on. */
+typedef struct cmoop_config {
+    int32_t variant;       /* CMOOP_VARIANT_* */
+    int32_t classes;       /* CLASSES           nsga_penalty.py:176 (10) / sa_nsga_penalty.py:102 (11) */
+    int32_t epochs;        /* EPOCHS            :177 */
+    int32_t batch;         /* BATCH_SIZE        :178 */
+    int32_t patience;      /* PATIENCE          :179 */
+    int32_t early_stop;    /* 1: EarlyStopping(monitor='val_loss') (:382); 0: run all epochs (throughput mode) */
+    int32_t restore_best;  /* restore_best_weights: 0 in nsga_penalty.py:382, 1 in sa_nsga_penalty.py:215 */
+    int32_t acc_readout;   /* 0: history['val_accuracy'][-1] (:384); 1: model.evaluate (sa_nsga_penalty.py:219) */
+    int32_t fpr_variant;   /* CMOOP_FPR_* */
+    int32_t shuffle;       /* Model.fit shuffle=True default */
+    int32_t eval_batch;    /* rows per inference launch (results do not depend on it) */
+    int32_t n_slots;       /* candidates in flight per GPU, each on its own HIP stream */
+    int32_t profile_every; /* >0: HIP-event-time the MFMA GEMM launches of every n-th train step */
+    int32_t reserved;
+    double lr;             /* 1e-3: optimizer='adam' (:377); LEARNING_RATE (:162) is unused by the reference */
+    double beta1, beta2, adam_eps; /* Keras Adam defaults .9 / .999 / 1e-7 */
+    double bn_eps, bn_momentum;    /* Keras BatchNormalization defaults 1e-3 / .99 */
+    double dropout;        /* 0.3 (nsga_penalty.py:323) */
+} cmoop_config;
+
+/* The module globals X_train, y_train, X_validation, y_validation (nsga_penalty.py:167),
+ * resident in HBM: features [n, T, F] fp32 (the trailing channel axis of :151-153 is
+ * implicit), labels [n] int32. */
+typedef struct cmoop_dataset {
+    const float* x_train;
+    const int32_t* y_train;
+    int64_t n_train;
+    const float* x_val;
+    const int32_t* y_val;
+    int64_t n_val;
+    int32_t T, F;
+} cmoop_dataset;
+
+int cmoop_abi_version(void);
+const char* cmoop_last_error(void);
+void cmoop_config_default(cmoop_config* cfg);
+
+/* compute_model_size_mb's count_params() without building a model (nsga_penalty.py:337-344);
+ * gene = {filters, kernel_size, use_bn, residual_blocks, fc_layers, use_dropout}. */
+int cmoop_param_count(const int32_t gene[6], int32_t variant, int32_t classes, int64_t* out);
+int cmoop_fwd_flops(const int32_t gene[6], int32_t variant, int32_t classes, int32_t T, int32_t F, double* out);
+
+/* compute_objectives_and_constraints' inner loop (nsga_penalty.py:426-427): evaluate n
+ * candidates; outputs are host arrays of length n (any may be NULL). */
+int cmoop_eval_population(const cmoop_config* cfg, const cmoop_dataset* ds, const int32_t* genes /* [n][6] */,
+                          const uint32_t* seeds /* [n] */, int32_t n, double* acc, double* size_mb, double* fpr,
+                          int32_t* epochs_run, double* val_loss, double* seconds);
+
+/* calculate_fpr on host label arrays (nsga_penalty.py:351-364 and variants) */
+int cmoop_calculate_fpr(const int32_t* y_true, const int32_t* y_pred, int64_t n, int32_t classes, int32_t fpr_variant,
+                        double* out);
+
+/* ---- audio front end (north-star addition; the reference loads pre-extracted features,
+ *      nsga_penalty.py:64-71) and prepare_dataset's StandardScaler (nsga_penalty.py:103-141) */
+int cmoop_logmel(const float* wav_dev /* [n_clips][n_samples] */, int64_t n_clips, int32_t n_samples,
+                 float* out_dev /* [n_clips][1+n_samples/160][40] */);
+int cmoop_standardize_fit(const float* x_dev, int64_t rows, int32_t cols, double* mean_host, double* scale_host);
+int cmoop_standardize_apply(float* x_dev, int64_t rows, int32_t cols, const double* mean_host, const double* scale_host);
+
+/* ---- HIP-event profile of the MFMA GEMM kernels sampled during cmoop_eval_population
+ *      (cls 0: igemm forward/dgrad kernel, cls 1: igemm wgrad kernel) */
+int cmoop_profile_reset(void);
+int cmoop_profile_get(int32_t cls, int64_t* launches, double* total_ms, double* total_flops);
+
+/* ---- single-candidate session (parity tests, smoke): one net on the library's stream */
+typedef struct cmoop_net cmoop_net;
+int cmoop_net_create(const int32_t gene[6], const cmoop_config* cfg, int32_t T, int32_t F, uint32_t seed, cmoop_net** out);
+int cmoop_net_destroy(cmoop_net* net);
+int cmoop_net_total_params(cmoop_net* net, int64_t* out);
+int cmoop_net_get_params(cmoop_net* net, float* host);       /* canonical order, see genes.py */
+int cmoop_net_set_params(cmoop_net* net, const float* host);
+int cmoop_net_get_grads(cmoop_net* net, float* host);
+int cmoop_net_train_step(cmoop_net* net, const float* x_dev, const int32_t* y_dev, const int32_t* idx_dev, int64_t row0,
+                         int32_t B);
+int cmoop_net_evaluate(cmoop_net* net, const float* x_dev, const int32_t* y_dev, int64_t n, double* loss_sum,
+                       int64_t* correct, int32_t* preds_dev);
+int cmoop_net_train_metrics(cmoop_net* net, double* loss_sum, int64_t* correct, int32_t reset);
+int cmoop_epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out_host);
+
+/* ---- kernel-level entry points (parity tests and the roofline leg of bench.py).
+ *      conv: y[B,OH,OW,Cout] = SAME-conv(x[B,H,W,Cin], w[Cout][KS][KS][Cin]) + bias, optional ReLU */
+int cmoop_conv_fwd(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int32_t B, int32_t H,
+                   int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t relu);
+/* dx = dgrad(dy) (optionally masked by x > 0), dw[Cout][KS][KS][Cin], db[Cout] */
+int cmoop_conv_bwd(const float* x_dev, const float* w_dev, const float* dy_dev, float* dx_dev, float* dw_dev, float* db_dev,
+                   int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t mask_relu);
+/* average ms per launch of the forward implicit GEMM over `iters` launches (HIP events on the library stream) */
+int cmoop_conv_fwd_time(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int32_t B, int32_t H,
+                        int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t iters, double* avg_ms);
+int cmoop_maxpool_fwd(const float* x_dev, float* y_dev, uint8_t* arg_dev, int32_t B, int32_t H, int32_t W, int32_t C);
+int cmoop_maxpool_bwd(const float* dy_dev, const uint8_t* arg_dev, const float* y_dev, float* dx_dev, int32_t B, int32_t H,
+                      int32_t W, int32_t C, int32_t mask_y_pos);
+int cmoop_device_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMOOP_H */

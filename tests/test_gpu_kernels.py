@@ -1,0 +1,211 @@
+"""GPU parity: individual HIP kernels (through the C ABI) vs the torch-CPU fp32 oracle ops.
+
+Floating-point kernels: tolerance is stated per test (fp32 accumulation in a
+different order than the CPU reference; relative to the tensor's max magnitude).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cmoop_audio_processing_amd import _lib
+from oracle.net import conv_same, maxpool_same
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5   # fp32 GEMM, K <= 12800: |err| <= TOL * max|ref| (MFMA is an exact fmaf chain)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def conv_ref(x_nhwc, w_ohwi, b, stride, relu):
+    x = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2)
+    y = conv_same(x, torch.from_numpy(w_ohwi), torch.from_numpy(b), stride)
+    if relu:
+        y = F.relu(y)
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, KS, stride, relu
+    (2, 13, 9, 16, 16, 3, 1, 0),
+    (3, 26, 10, 32, 64, 5, 1, 1),
+    (2, 51, 20, 16, 32, 1, 2, 0),      # skip projection: 1x1 stride 2 SAME, odd height
+    (2, 7, 5, 64, 128, 3, 1, 0),
+    (1, 13, 5, 256, 512, 5, 1, 1),     # K = 6400, two N tiles
+    (64, 1, 1, 256, 64, 1, 1, 1),      # dense as 1x1 conv
+    (5, 1, 1, 64, 10, 1, 1, 0),        # output layer: N = classes
+    (3, 1, 1, 64, 35, 1, 1, 0),
+    (2, 21, 12, 1, 16, 3, 1, 1),       # first layer (C_in = 1), direct kernel
+    (2, 21, 12, 1, 64, 5, 1, 0),
+    (1, 101, 40, 1, 32, 5, 1, 1),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,KS,stride,relu", CONV_CASES)
+def test_conv_fwd(B, H, W, Cin, Cout, KS, stride, relu):
+    rs = np.random.RandomState(B * 1000 + H + Cin + Cout)
+    x = rs.randn(B, H, W, Cin).astype(np.float32)
+    w = (rs.randn(Cout, KS, KS, Cin) / np.sqrt(KS * KS * Cin)).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    OH, OW = -(-H // stride), -(-W // stride)
+    y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().cmoop_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), B, H, W, Cin, Cout, KS, stride, relu))
+    ref = conv_ref(x, w, b, stride, relu)
+    e = rel(y.cpu().numpy(), ref)
+    print(f"conv_fwd {B,H,W,Cin,Cout,KS,stride} rel={e:.2e}")
+    assert e < TOL
+
+
+BWD_CASES = [
+    (2, 13, 9, 16, 16, 3, 1, 1),
+    (3, 26, 10, 32, 64, 5, 1, 0),
+    (2, 51, 20, 16, 32, 1, 2, 1),      # strided 1x1: scatter-accumulate dgrad
+    (2, 7, 5, 64, 128, 3, 1, 1),
+    (64, 1, 1, 128, 64, 1, 1, 1),
+    (7, 1, 1, 64, 10, 1, 1, 1),        # output layer dgrad (small VALU kernel), N % 4 != 0 bias path
+    (64, 13, 5, 16, 32, 3, 1, 0),      # long reduction -> several wgrad slices
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,KS,stride,mask", BWD_CASES)
+def test_conv_bwd(B, H, W, Cin, Cout, KS, stride, mask):
+    rs = np.random.RandomState(B * 77 + H + Cin + Cout)
+    x = rs.randn(B, H, W, Cin).astype(np.float32)
+    if mask:
+        x = np.maximum(x, 0).astype(np.float32)     # a ReLU output: dgrad epilogue masks by x > 0
+    w = (rs.randn(Cout, KS, KS, Cin) / np.sqrt(KS * KS * Cin)).astype(np.float32)
+    OH, OW = -(-H // stride), -(-W // stride)
+    dy = rs.randn(B, OH, OW, Cout).astype(np.float32)
+    # reference: autograd through relu(pre) where x = relu(pre): grad wrt pre = grad wrt x * (x > 0)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wt = torch.from_numpy(w).clone().requires_grad_(True)
+    bt = torch.zeros(Cout, requires_grad=True)
+    y = conv_same(xt, wt, bt, stride)
+    y.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    dx_ref = xt.grad.permute(0, 2, 3, 1).numpy()
+    if mask:
+        dx_ref = dx_ref * (x > 0)
+    dx = torch.full((B, H, W, Cin), float("nan"), device="cuda")
+    dw = torch.full((Cout, KS, KS, Cin), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda")
+    xd, wd, dyd = dev(x), dev(w), dev(dy)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().cmoop_conv_bwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(dyd), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
+                                         B, H, W, Cin, Cout, KS, stride, mask))
+    e_dx, e_dw, e_db = rel(dx.cpu().numpy(), dx_ref), rel(dw.cpu().numpy(), wt.grad.numpy()), rel(db.cpu().numpy(), bt.grad.numpy())
+    print(f"conv_bwd {B,H,W,Cin,Cout,KS,stride} dx={e_dx:.2e} dw={e_dw:.2e} db={e_db:.2e}")
+    assert e_dx < TOL and e_dw < 5e-5 and e_db < 5e-5
+
+
+def test_conv1_bwd():
+    B, H, W, Cout, KS = 3, 21, 12, 32, 5
+    rs = np.random.RandomState(5)
+    x = rs.randn(B, H, W, 1).astype(np.float32)
+    w = rs.randn(Cout, KS, KS, 1).astype(np.float32)
+    dy = rs.randn(B, H, W, Cout).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    wt = torch.from_numpy(w).clone().requires_grad_(True)
+    bt = torch.zeros(Cout, requires_grad=True)
+    conv_same(xt, wt, bt, 1).backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    dw = torch.full((Cout, KS, KS, 1), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda")
+    xd, wd, dyd = dev(x), dev(w), dev(dy)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().cmoop_conv_bwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(dyd), None, _lib.ptr(dw), _lib.ptr(db), B, H, W, 1, Cout, KS, 1, 0))
+    assert rel(dw.cpu().numpy(), wt.grad.numpy()) < 5e-5 and rel(db.cpu().numpy(), bt.grad.numpy()) < 5e-5
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 101, 40, 16), (3, 51, 20, 32), (2, 13, 5, 64), (2, 7, 3, 128), (1, 1, 1, 16)])
+def test_maxpool_same_fwd_bwd(B, H, W, C):
+    rs = np.random.RandomState(H * W)
+    x = rs.randn(B, H, W, C).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    y_ref = maxpool_same(xt)
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    dy = rs.randn(B, OH, OW, C).astype(np.float32)
+    y_ref.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    y = torch.empty((B, OH, OW, C), device="cuda")
+    arg = torch.empty((B, OH, OW, C), dtype=torch.uint8, device="cuda")
+    dx = torch.full((B, H, W, C), float("nan"), device="cuda")
+    xd, dyd = dev(x), dev(dy)
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    _lib.check(L.cmoop_maxpool_fwd(_lib.ptr(xd), _lib.ptr(y), _lib.ptr(arg), B, H, W, C))
+    _lib.check(L.cmoop_maxpool_bwd(_lib.ptr(dyd), _lib.ptr(arg), _lib.ptr(y), _lib.ptr(dx), B, H, W, C, 0))
+    assert np.array_equal(y.cpu().numpy(), y_ref.detach().permute(0, 2, 3, 1).numpy())          # exact
+    assert np.array_equal(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())                # exact
+
+
+def test_conv_fwd_full_size_rows():
+    """BASELINE config size (B=64, 101x40): conv is local, so rows of the first and last
+    sample must equal the CPU reference run on just those two samples."""
+    B, H, W, Cin, Cout, KS = 64, 101, 40, 16, 32, 3
+    rs = np.random.RandomState(9)
+    x = rs.randn(B, H, W, Cin).astype(np.float32)
+    w = (rs.randn(Cout, KS, KS, Cin) / 12).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    y = torch.empty((B, H, W, Cout), device="cuda")
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().cmoop_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), B, H, W, Cin, Cout, KS, 1, 0))
+    yh = y.cpu().numpy()
+    ref = conv_ref(x[[0, 63]], w, b, 1, 0)
+    assert rel(yh[[0, 63]], ref) < TOL
+    # linearity in the input: conv(2x) - bias == 2 (conv(x) - bias)
+    x2 = dev(2 * x)
+    y2 = torch.empty_like(y)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().cmoop_conv_fwd(_lib.ptr(x2), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y2), B, H, W, Cin, Cout, KS, 1, 0))
+    assert rel((y2.cpu().numpy() - b), 2 * (yh - b)) < 1e-5
+
+
+def test_frontend_logmel_and_standardize():
+    """Front end vs oracle/frontend.py (numpy float64 restatement of librosa's algorithm).
+    Tolerance 2e-4 absolute on log-mel (fp32 radix-2 FFT vs float64 pocketfft)."""
+    from cmoop_audio_processing_amd import frontend as fe
+    from oracle import frontend as ofe
+    rs = np.random.RandomState(3)
+    n, L = 6, 16000
+    t = np.arange(L) / 16000.0
+    wav = np.stack([0.5 * np.sin(2 * np.pi * (200 + 300 * i) * t) + 0.3 * rs.randn(L) for i in range(n)]).astype(np.float32)
+    wav[0, :] *= 0.01
+    out = fe.log_mel(dev(wav))
+    ref = ofe.log_mel(wav)
+    assert out.shape == (n, 101, 40)
+    err = np.abs(out.cpu().numpy() - ref).max()
+    print("logmel max abs err", err)
+    assert err < 2e-4
+    # StandardScaler parity: stats 1e-6 relative, transformed values 1e-5 absolute
+    feats = out.clone()
+    mean, scale = fe.standardize_fit(feats)
+    m_ref, s_ref = ofe.scaler_fit(out.cpu().numpy())
+    assert np.abs(mean - m_ref).max() < 1e-5 * (1 + np.abs(m_ref).max()) and np.abs(scale - s_ref).max() < 1e-5 * s_ref.max()
+    fe.standardize_apply(feats, mean, scale)
+    assert np.abs(feats.cpu().numpy() - ofe.scaler_transform(out.cpu().numpy(), mean, scale)).max() < 1e-5
+
+
+def test_frontend_edge_cases():
+    from cmoop_audio_processing_amd import frontend as fe
+    from oracle import frontend as ofe
+    # silence -> log(eps); very short clip (one hop -> 2 frames); non multiple-of-4 length (global-memory path)
+    z = torch.zeros((2, 16000), device="cuda")
+    assert np.allclose(fe.log_mel(z).cpu().numpy(), np.log(1e-6), atol=1e-5)
+    rs = np.random.RandomState(4)
+    for L in (160, 1601, 4000):
+        w = rs.randn(3, L).astype(np.float32)
+        out = fe.log_mel(dev(w)).cpu().numpy()
+        assert out.shape == (3, 1 + L // 160, 40)
+        assert np.abs(out - ofe.log_mel(w)).max() < 2e-4
+    assert fe.log_mel(torch.zeros((0, 16000), device="cuda")).shape == (0, 101, 40)

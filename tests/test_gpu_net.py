@@ -1,0 +1,206 @@
+"""GPU parity: whole-candidate training / inference through the C ABI vs the oracle.
+
+The oracle (oracle/net.py) takes gradients from torch autograd, so these tests
+check every hand-written backward kernel.  fp32 everywhere; tolerances are
+relative to each tensor's max magnitude and stated at the assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+from cmoop_audio_processing_amd import EvalConfig, PopulationEvaluator, genes as G
+from cmoop_audio_processing_amd.session import NetSession
+from oracle import metrics as OM
+from oracle import net as ON
+
+pytestmark = pytest.mark.gpu
+
+
+def ocfg(cfg: EvalConfig) -> ON.OracleConfig:
+    return ON.OracleConfig(variant=G.VARIANT_NAMES[cfg.variant], classes=cfg.classes, epochs=cfg.epochs, batch=cfg.batch,
+                           patience=cfg.patience, early_stop=cfg.early_stop, restore_best=cfg.restore_best,
+                           acc_readout="last" if cfg.acc_readout == "last" else "evaluate",
+                           fpr_variant=OM.FPR_V1 if cfg.fpr_variant == "v1" else (OM.FPR_V1_QUIRK if cfg.fpr_variant == "v1_quirk" else OM.FPR_V3),
+                           lr=cfg.lr, dropout=cfg.dropout, shuffle=cfg.shuffle)
+
+
+def make_data(n, T, F, classes, seed):
+    rs = np.random.RandomState(seed)
+    y = rs.randint(0, classes, size=n).astype(np.int32)
+    proto = rs.randn(classes, T, F).astype(np.float32)
+    X = (0.8 * proto[y] + rs.randn(n, T, F)).astype(np.float32)
+    return X, y
+
+
+def per_tensor_err(gene, variant, classes, a, b):
+    """max-abs error of each canonical tensor relative to that tensor's max magnitude."""
+    out, off = {}, 0
+    for name, shape, role in G.param_tensors(gene, variant, classes):
+        n = int(np.prod(shape))
+        ra, rb = a[off:off + n].astype(np.float64), b[off:off + n].astype(np.float64)
+        out[name] = float(np.abs(ra - rb).max() / (np.abs(rb).max() + 1e-12))
+        off += n
+    return out
+
+
+GENES = [
+    # gene (filters, kernel, bn, res_blocks, fc_layers, dropout), variant
+    ((16, 3, 0, 1, 1, 0), "A"),
+    ((16, 3, 1, 1, 2, 1), "A"),
+    ((32, 5, 1, 2, 3, 0), "A"),
+    ((16, 5, 0, 3, 4, 1), "A"),
+    ((16, 3, 0, 1, 1, 0), "B"),
+    ((16, 3, 1, 2, 2, 1), "B"),
+    ((32, 5, 1, 3, 4, 0), "B"),
+    ((64, 3, 0, 2, 1, 1), "B"),
+]
+
+
+@pytest.mark.parametrize("gene,variant", GENES)
+def test_init_step_grads_and_eval_parity(gene, variant):
+    T, F, classes, B, seed = 21, 12, 10, 24, 1234
+    cfg = EvalConfig(variant=variant, classes=classes, batch=32, eval_batch=16)
+    X, y = make_data(80, T, F, classes, 1)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    v = G.VARIANT_NAMES[variant]
+    onet = ON.OracleNet(gene, ocfg(cfg), seed)
+    with NetSession(gene, cfg, T, F, seed) as net:
+        assert net.n_params == G.param_count(gene, v, classes) == onet.count_params()
+        # 1. seeded glorot init: bit-exact
+        assert np.array_equal(net.get_params(), onet.get_flat())
+        # 2. inference from identical weights: loss 1e-5 rel, identical predictions
+        l_o, a_o, p_o = onet.evaluate(X, y)
+        l_g, a_g, p_g = net.evaluate(Xd, yd)
+        assert abs(l_g - l_o) < 1e-5 * max(1.0, abs(l_o)), (l_g, l_o)
+        assert np.array_equal(p_g.cpu().numpy(), p_o) and a_g == a_o
+        # 3. one training step on rows idx[4:4+B]: gradients, updated weights, BN moving stats
+        idx = np.random.RandomState(2).permutation(80).astype(np.int32)
+        idxd = torch.from_numpy(idx).cuda()
+        net.train_step(Xd, yd, idxd, row0=4, B=B)
+        lo, co = onet.train_step(X[idx[4:4 + B]], y[idx[4:4 + B]])
+        lg, cg = net.train_metrics()
+        assert abs(lg - lo) < 2e-5 * max(1.0, abs(lo)) and cg == co
+        gerr = per_tensor_err(gene, v, classes, net.get_grads(), onet.grads_flat())
+        worst = max(gerr, key=gerr.get)
+        print(f"{variant}{gene} worst grad err {worst}: {gerr[worst]:.2e}")
+        # fp32, different summation order; BN nets amplify (cancellation in dx): 5e-4 of the tensor's max
+        assert gerr[worst] < 5e-4, gerr
+        perr = per_tensor_err(gene, v, classes, net.get_params(), onet.get_flat())
+        worstp = max(perr, key=perr.get)
+        # Adam's first step is +-lr for every weight regardless of |g|: sign flips of ~0 gradients
+        # move a weight by 2*lr, so compare at 2.5*lr absolute instead of relative
+        d = np.abs(net.get_params() - onet.get_flat())
+        print(f"   worst param err {worstp}: {perr[worstp]:.2e}; max abs diff {d.max():.2e}")
+        assert d.max() <= 2.5 * cfg.lr
+        # 4. four more steps, then inference with the moving statistics
+        for s in range(4):
+            r0 = 4 + (s + 1) * 8
+            net.train_step(Xd, yd, idxd, row0=r0, B=B)
+            onet.train_step(X[idx[r0:r0 + B]], y[idx[r0:r0 + B]])
+        l_o, a_o, p_o = onet.evaluate(X, y)
+        l_g, a_g, p_g = net.evaluate(Xd, yd)
+        print(f"   after 5 steps: loss gpu {l_g:.6f} oracle {l_o:.6f}; preds differing {(p_g.cpu().numpy() != p_o).sum()}")
+        assert abs(l_g - l_o) < 5e-3 * max(1.0, abs(l_o))
+
+
+def test_partial_batch_and_full_feature_size():
+    """T x F = 101 x 40 (BASELINE feature size), batch 5 < configured 64 (Keras keeps the last partial batch)."""
+    gene, variant, classes, seed = (16, 3, 1, 1, 1, 0), "A", 10, 7
+    cfg = EvalConfig(variant=variant, classes=classes, batch=64, eval_batch=8)
+    X, y = make_data(12, 101, 40, classes, 5)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    onet = ON.OracleNet(gene, ocfg(cfg), seed)
+    with NetSession(gene, cfg, 101, 40, seed) as net:
+        net.train_step(Xd, yd, None, row0=3, B=5)
+        onet.train_step(X[3:8], y[3:8])
+        gerr = per_tensor_err(gene, 0, classes, net.get_grads(), onet.grads_flat())
+        assert max(gerr.values()) < 5e-4, gerr
+        l_o, a_o, p_o = onet.evaluate(X, y)
+        l_g, a_g, p_g = net.evaluate(Xd, yd)
+        assert abs(l_g - l_o) < 1e-4 * max(1.0, abs(l_o))
+
+
+def test_classes_35_and_11():
+    for classes in (11, 35):
+        gene, seed = (16, 3, 0, 1, 2, 0), 3
+        cfg = EvalConfig(variant="B", classes=classes, batch=16, eval_batch=16)
+        X, y = make_data(32, 21, 12, classes, classes)
+        Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+        onet = ON.OracleNet(gene, ocfg(cfg), seed)
+        with NetSession(gene, cfg, 21, 12, seed) as net:
+            net.train_step(Xd, yd, None, row0=0, B=16)
+            onet.train_step(X[:16], y[:16])
+            gerr = per_tensor_err(gene, 1, classes, net.get_grads(), onet.grads_flat())
+            assert max(gerr.values()) < 5e-4, gerr
+
+
+PROTOCOLS = [
+    ("nsga_penalty", (16, 3, 0, 1, 1, 0)),       # A, last-epoch accuracy, no restore, y_true quirk
+    ("sa_nsga_penalty", (16, 3, 1, 1, 2, 1)),    # B, restore_best, evaluate(), V1
+    ("sa_nsga_local", (16, 5, 0, 2, 1, 0)),      # B, V3
+]
+
+
+@pytest.mark.parametrize("preset,gene", PROTOCOLS)
+def test_evaluate_individual_protocol_parity(preset, gene):
+    """Bounded-horizon end-to-end parity (SURVEY §7 hard part 1): 6 epochs x 4 steps with early
+    stopping active.  size_mb bit-exact; val-loss-driven epoch count equal; accuracy within
+    2/N_val and FPR within 2e-2 of the oracle (chaotic fp32 training: a single flipped
+    prediction is 1/N_val), and -- the 1e-3 gate -- metrics from IDENTICAL weights are
+    covered by test_init_step_grads_and_eval_parity (identical predictions)."""
+    classes = 10 if preset != "sa_nsga_penalty" else 11
+    cfg = EvalConfig.preset(preset, classes=classes, epochs=6, patience=2, batch=32, eval_batch=64, seed=11, n_slots=1)
+    Xtr, ytr = make_data(128, 21, 12, classes, 21)
+    Xva, yva = make_data(96, 21, 12, classes, 22)
+    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+    acc, size_mb, fpr = ev.evaluate_individual(G.gene_to_hparams(gene))
+    o_acc, o_size, o_fpr, o_epochs = ON.evaluate_individual(gene, ocfg(cfg), Xtr, ytr, Xva, yva, seed=11)
+    print(preset, "gpu", (acc, size_mb, fpr, ev.last_epochs_run), "oracle", (o_acc, o_size, o_fpr, o_epochs))
+    assert size_mb == o_size == G.model_size_mb(gene, G.VARIANT_NAMES[cfg.variant], classes)
+    assert abs(acc - o_acc) <= 2.0 / 96 + 1e-9
+    assert abs(fpr - o_fpr) <= 2e-2
+    assert abs(ev.last_epochs_run[0] - o_epochs) <= 1
+
+
+def test_population_schema_determinism_and_problem_shim():
+    classes = 10
+    cfg = EvalConfig.preset("nsga_penalty", epochs=2, batch=32, eval_batch=64, seed=5, n_slots=3, early_stop=False)
+    Xtr, ytr = make_data(96, 21, 12, classes, 31)
+    Xva, yva = make_data(64, 21, 12, classes, 32)
+    import random
+    rng = random.Random(0)
+    pop = [G.random_hparams(rng) for _ in range(5)]
+    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+    res = ev.compute_objectives_and_constraints(pop)
+    assert [set(r) for r in res] == [{"hparams", "objs", "CV"}] * 5
+    for hp, r in zip(pop, res):
+        assert r["hparams"] is hp                                   # reference, not a copy (nsga_penalty.py:438)
+        assert r["objs"][1] == G.model_size_mb(G.normalize_hparams(hp), 0, classes)
+        acc, size, fpr = -r["objs"][0], r["objs"][1], r["objs"][2]
+        assert r["CV"] == max(0.0, 0.9 - acc) + max(0.0, size - 2.5) + max(0.0, fpr - 0.1)
+        assert 0.0 <= acc <= 1.0 and 0.0 <= fpr <= 0.1 + 1e-12     # quirk: FPR <= 1/C
+    assert ev.last_epochs_run == [2] * 5
+    # bit-reproducible: same seeds, different slot count -> identical objective vectors
+    ev2 = PopulationEvaluator(Xtr, ytr, Xva, yva, EvalConfig.preset("nsga_penalty", epochs=2, batch=32, eval_batch=64, seed=5, n_slots=1, early_stop=False))
+    res2 = ev2.compute_objectives_and_constraints(pop)
+    assert [r["objs"] for r in res] == [r["objs"] for r in res2]
+    # empty population and pymoo-style shim
+    assert ev.compute_objectives_and_constraints([]) == []
+    from cmoop_audio_processing_amd import AudioNASProblem
+    out = {}
+    AudioNASProblem(ev2)._evaluate(np.array([[0.0, 0.0, 1.0, 0.0, 0.0, 1.0], [0.5, 1.0, 0.0, 0.5, 1.0, 0.0]]), out)
+    assert out["F"].shape == (2, 3) and out["G"].shape == (2, 3)
+    assert np.allclose(out["G"][:, 1], out["F"][:, 1] - 2.5)
+
+
+def test_bad_inputs_fail_loudly():
+    from cmoop_audio_processing_amd import _lib
+    cfg = EvalConfig(epochs=1)
+    Xtr, ytr = make_data(8, 21, 12, 10, 1)
+    ev = PopulationEvaluator(Xtr, ytr, Xtr, ytr, cfg)
+    with pytest.raises(ValueError):
+        ev.evaluate_individual({"filters": 48, "kernel_size": 3, "use_bn": True, "residual_blocks": 1, "fc_layers": 1, "use_dropout": False})
+    with pytest.raises(KeyError):
+        ev.evaluate_individual({"filters": 16})
+    with pytest.raises(_lib.CmoopError):
+        NetSession((16, 3, 0, 1, 1, 0), EvalConfig(classes=1), 21, 12, 0)

@@ -1,0 +1,108 @@
+"""CPU: host logic, the C-ABI library's exports, and the N>1 sharding path over gloo."""
+import ctypes as C
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cmoop_audio_processing_amd import _lib, genes as G
+from cmoop_audio_processing_amd.evaluator import EvalConfig, calculate_fpr, compute_model_size_mb, sharded_map
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    _lib.build()
+    L = _lib.lib()
+    names = _lib.declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.cmoop_abi_version() == 1
+
+
+def test_abi_host_only_closed_forms_match_python():
+    L = _lib.lib()
+    for variant in (0, 1):
+        for classes in (10, 11, 35):
+            for g in G.all_genes()[::7]:
+                arr = (C.c_int32 * 6)(*g)
+                n, f = C.c_int64(), C.c_double()
+                _lib.check(L.cmoop_param_count(arr, variant, classes, C.byref(n)))
+                _lib.check(L.cmoop_fwd_flops(arr, variant, classes, 101, 40, C.byref(f)))
+                assert n.value == G.param_count(g, variant, classes)
+                assert f.value == float(G.fwd_flops_per_sample(g, variant, classes, 101, 40))
+    bad = (C.c_int32 * 6)(48, 3, 1, 1, 1, 0)
+    n = C.c_int64()
+    assert L.cmoop_param_count(bad, 0, 10, C.byref(n)) != 0
+    assert b"search space" in L.cmoop_last_error()
+
+
+def test_abi_fpr_matches_reference_goldens(golden_dir):
+    import json
+    for c in json.load(open(os.path.join(golden_dir, "fpr_golden.json")))["cases"]:
+        assert calculate_fpr(c["y_true"], c["y_pred"], c["C"], "v1") == pytest.approx(c["v1"], abs=1e-15)
+        assert calculate_fpr(c["y_true"], c["y_pred"], c["C"], "v3") == pytest.approx(c["v3"], abs=1e-15)
+        assert calculate_fpr(c["y_true"], c["y_pred"], c["C"], "v1_quirk") == pytest.approx(c["v1_quirk"], abs=1e-15)
+
+
+def test_abi_permutation_matches_oracle_rng():
+    from cmoop_audio_processing_amd.session import epoch_permutation
+    from oracle import rng
+    for seed, epoch, n in ((0, 0, 1), (1, 2, 17), (123456789, 299, 24000)):
+        p = epoch_permutation(seed, epoch, n)
+        assert np.array_equal(p, rng.epoch_permutation(seed, epoch, n))
+        assert sorted(p.tolist()) == list(range(n))
+
+
+def test_presets_follow_the_reference_scripts():
+    a = EvalConfig.preset("nsga_penalty")
+    assert (a.variant, a.classes, a.restore_best, a.acc_readout, a.fpr_variant) == ("A", 10, False, "last", "v1_quirk")
+    assert (a.min_accuracy, a.max_model_size, a.max_fpr, a.epochs, a.batch, a.patience) == (0.9, 2.5, 0.1, 300, 64, 5)
+    b = EvalConfig.preset("sa_nsga_penalty")
+    assert (b.variant, b.classes, b.restore_best, b.acc_readout, b.fpr_variant) == ("B", 11, True, "evaluate", "v1")
+    assert (b.min_accuracy, b.max_fpr) == (0.75, 0.09)
+    assert EvalConfig.preset("sa_nsga_local").fpr_variant == "v3"
+    with pytest.raises(KeyError):
+        EvalConfig.preset("nope")
+
+
+def test_size_mb_helper_and_hparams_normalisation():
+    hp = {"filters": np.int64(32), "kernel_size": 3, "use_bn": 1, "residual_blocks": np.int32(2), "fc_layers": 2, "use_dropout": 0}
+    assert compute_model_size_mb(hp, "A", 10) == 324074 * 4 / 1024 ** 2
+    assert G.normalize_hparams(hp) == (32, 3, 1, 2, 2, 0)
+    with pytest.raises(ValueError):
+        G.normalize_hparams(dict(hp, kernel_size=4))
+
+
+def test_random_hparams_draws_like_the_reference():
+    # initialize_population: random.choice per gene in dict-key order (nsga_penalty.py:405-412)
+    r1, r2 = random.Random(3), random.Random(3)
+    hp = G.random_hparams(r1)
+    exp = {"filters": r2.choice([16, 32, 64]), "kernel_size": r2.choice([3, 5]), "use_bn": r2.choice([True, False]),
+           "residual_blocks": r2.choice([1, 2, 3]), "fc_layers": r2.choice([1, 2, 3, 4]), "use_dropout": r2.choice([True, False])}
+    assert hp == exp and list(hp) == list(exp)
+
+
+def test_sharded_map_without_process_group_is_local():
+    out = sharded_map(lambda idx: np.array([[i, 2 * i] for i in idx], dtype=np.float64), [3.0, 1.0, 2.0], 2)
+    assert out.tolist() == [[0, 0], [1, 2], [2, 4]]
+
+
+def test_sharding_world_size_2_gloo():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "tests", "_gloo_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "GLOO_WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cmoop_audio_processing_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
