@@ -159,12 +159,22 @@ int cmoop_standardize_apply(float* x_dev, int64_t rows, int32_t cols, const doub
 
 // ---- profile -------------------------------------------------------------------
 int cmoop_profile_reset(void) { return guard([] { profile_totals().reset(); }); }
-int cmoop_profile_get(int32_t cls, int64_t* launches, double* total_ms, double* total_flops) {
+int cmoop_profile_count(int32_t* out) {
     return guard([&] {
-        CMOOP_REQUIRE(cls == 0 || cls == 1, "profile class must be 0 or 1");
         ProfileTotals& t = profile_totals();
         std::lock_guard<std::mutex> l(t.mu);
-        *launches = t.launches[cls]; *total_ms = t.ms[cls]; *total_flops = t.flops[cls];
+        *out = (int32_t)t.by_kernel.size();
+    });
+}
+int cmoop_profile_entry(int32_t i, char* name, int32_t name_cap, int64_t* launches, double* total_ms, double* total_flops) {
+    return guard([&] {
+        ProfileTotals& t = profile_totals();
+        std::lock_guard<std::mutex> l(t.mu);
+        CMOOP_REQUIRE(i >= 0 && i < (int)t.by_kernel.size() && name_cap > 0, "profile entry out of range");
+        auto it = t.by_kernel.begin();
+        std::advance(it, i);
+        std::snprintf(name, name_cap, "%s", it->first.c_str());
+        *launches = it->second.launches; *total_ms = it->second.ms; *total_flops = it->second.flops;
     });
 }
 

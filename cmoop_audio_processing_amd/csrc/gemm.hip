@@ -185,10 +185,10 @@ static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDe
     CMOOP_HIP(hipGetLastError());
 }
 
-void launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& cg, const GemmEpilogue& ep,
-                      hipStream_t s) {
+int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& cg, const GemmEpilogue& ep,
+                     hipStream_t s) {
     GeomDev g = to_dev(cg);
-    if (g.M == 0) return;
+    if (g.M == 0) return 0;
     EpiDev e;
     e.bias = ep.bias; e.mask = ep.mask; e.mask_scale = ep.mask_scale; e.relu = ep.relu;
     e.accumulate = ep.accumulate; e.out_stride = ep.out_stride; e.OHf = ep.OHf; e.OWf = ep.OWf;
@@ -207,6 +207,7 @@ void launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom&
     else if (N <= 64) CMOOP_FWD(64);
     else CMOOP_FWD(128);
 #undef CMOOP_FWD
+    return (N <= 16 ? 16 : N <= 32 ? 32 : N <= 64 ? 64 : 128) * 100 + (bk32 ? 32 : 16);
 }
 
 // ---------------------------------------------------------------------------
@@ -336,9 +337,9 @@ int wgrad_slices(const ConvGeom& g) {
     return S;
 }
 
-void launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s) {
+int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s) {
     GeomDev g = to_dev(cg);
-    if (g.M == 0) return;
+    if (g.M == 0) return 0;
     int rps = cdiv(g.M, S);
     rps = cdiv(rps, 32) * 32;
     const int N = g.Cout;
@@ -348,6 +349,7 @@ void launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeo
     else if (bco == 32) hipLaunchKernelGGL((igemm_wgrad_kernel<32>), grid, dim3(256), 0, s, X, dY, P, g, rps);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<64>), grid, dim3(256), 0, s, X, dY, P, g, rps);
     CMOOP_HIP(hipGetLastError());
+    return bco;
 }
 
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ P, float* __restrict__ out, int S,

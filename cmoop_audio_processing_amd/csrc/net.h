@@ -5,7 +5,9 @@
 #pragma once
 #include "kernels.h"
 #include <atomic>
+#include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace cmoop {
@@ -29,17 +31,17 @@ double fwd_flops_per_sample(const int32_t g[6], int variant, int classes, int T,
 void validate_gene(const int32_t g[6]);
 
 // HIP-event sampling of the MFMA GEMM kernels inside the timed region (bench.py roofline)
-struct ProfileTotals {
+struct ProfileEntry { double ms = 0, flops = 0; long long launches = 0; };
+struct ProfileTotals {   // keyed by kernel instantiation name, e.g. "igemm_fwd_kernel<128,32>"
     std::mutex mu;
-    double ms[2] = {0, 0}, flops[2] = {0, 0};
-    long long launches[2] = {0, 0};
-    void reset() { std::lock_guard<std::mutex> l(mu); ms[0] = ms[1] = flops[0] = flops[1] = 0; launches[0] = launches[1] = 0; }
+    std::map<std::string, ProfileEntry> by_kernel;
+    void reset() { std::lock_guard<std::mutex> l(mu); by_kernel.clear(); }
 };
 ProfileTotals& profile_totals();
 
 struct GemmHook {   // brackets every MFMA GEMM launch (HIP-event sampling)
     virtual void before(int cls, double flops) = 0;
-    virtual void after() = 0;
+    virtual void after(int code) = 0;
     virtual ~GemmHook() {}
 };
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
@@ -78,7 +80,7 @@ struct Op {
 class Net : public GemmHook {
   public:
     void before(int cls, double flops) override;
-    void after() override;
+    void after(int code) override;
     Net(const int32_t gene[6], const NetConfig& cfg, int T, int F, uint32_t seed, hipStream_t stream);
     ~Net();
     Net(const Net&) = delete;
@@ -125,7 +127,7 @@ class Net : public GemmHook {
     int logits_ = -1;
     long long step_ = 0, iterations_ = 0;
     bool profiling_now_ = false, hook_live_ = false;
-    struct EvPair { hipEvent_t a, b; double flops; int cls; };
+    struct EvPair { hipEvent_t a, b; double flops; int cls, code; };
     std::vector<EvPair> ev_pool_;
     size_t ev_used_ = 0;
 };

@@ -322,9 +322,10 @@ void Net::before(int cls, double flops) {
     ev_pool_[ev_used_].flops = flops;
     ev_pool_[ev_used_].cls = cls;
 }
-void Net::after() {
+void Net::after(int code) {
     if (!hook_live_) return;
     CMOOP_HIP(hipEventRecord(ev_pool_[ev_used_].b, stream_));
+    ev_pool_[ev_used_].code = code;
     ++ev_used_;
     hook_live_ = false;
 }
@@ -335,8 +336,8 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
     const int M = g.M(), N = g.Cout, K = g.K();
     const int S = wgrad_slices(g);
     if (hook) hook->before(1, 2.0 * M * (double)N * K);
-    launch_igemm_wgrad(X, dY, wgrad_ws, g, S, s);
-    if (hook) hook->after();
+    const int code = launch_igemm_wgrad(X, dY, wgrad_ws, g, S, s);
+    if (hook) hook->after(code);
     launch_reduce_slices(wgrad_ws, dW, S, (int64_t)N * K, s);
     if (N % 4 == 0) {
         const int nb = colreduce_blocks(M, N);
@@ -374,14 +375,13 @@ void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGe
     e.mask = mask;
     e.mask_scale = mask_scale;
     if (hook) hook->before(0, 2.0 * gd.M() * (double)gd.Cout * gd.K());
-    launch_igemm_fwd(dY, wd_ws, dX, gd, e, s);
-    if (hook) hook->after();
+    const int code = launch_igemm_fwd(dY, wd_ws, dX, gd, e, s);
+    if (hook) hook->after(code);
 }
 
 void Net::run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e) {
     before(cls, 2.0 * g.M() * (double)g.Cout * g.K());
-    launch_igemm_fwd(X, Wt, Y, g, e, stream_);
-    after();
+    after(launch_igemm_fwd(X, Wt, Y, g, e, stream_));
 }
 
 void Net::drain_profile() {
@@ -391,9 +391,14 @@ void Net::drain_profile() {
     for (size_t i = 0; i < ev_used_; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b) == hipSuccess) {
-            t.ms[ev_pool_[i].cls] += ms;
-            t.flops[ev_pool_[i].cls] += ev_pool_[i].flops;
-            t.launches[ev_pool_[i].cls] += 1;
+            const int code = ev_pool_[i].code;
+            const std::string name = ev_pool_[i].cls == 0
+                ? "igemm_fwd_kernel<" + std::to_string(code / 100) + "," + std::to_string(code % 100) + ">"
+                : "igemm_wgrad_kernel<" + std::to_string(code) + ">";
+            ProfileEntry& e = t.by_kernel[name];
+            e.ms += ms;
+            e.flops += ev_pool_[i].flops;
+            e.launches += 1;
         }
     }
     ev_used_ = 0;

@@ -97,9 +97,10 @@ int cmoop_standardize_fit(const float* x_dev, int64_t rows, int32_t cols, double
 int cmoop_standardize_apply(float* x_dev, int64_t rows, int32_t cols, const double* mean_host, const double* scale_host);
 
 /* ---- HIP-event profile of the MFMA GEMM kernels sampled during cmoop_eval_population
- *      (cls 0: igemm forward/dgrad kernel, cls 1: igemm wgrad kernel) */
+ *      (cfg.profile_every): one entry per kernel instantiation, named as rocprofv3 names it */
 int cmoop_profile_reset(void);
-int cmoop_profile_get(int32_t cls, int64_t* launches, double* total_ms, double* total_flops);
+int cmoop_profile_count(int32_t* out);
+int cmoop_profile_entry(int32_t i, char* name, int32_t name_cap, int64_t* launches, double* total_ms, double* total_flops);
 
 /* ---- single-candidate session (parity tests, smoke): one net on the library's stream */
 typedef struct cmoop_net cmoop_net;

@@ -33,12 +33,17 @@ def make_data(n, T, F, classes, seed):
 
 
 def per_tensor_err(gene, variant, classes, a, b):
-    """max-abs error of each canonical tensor relative to that tensor's max magnitude."""
+    """max-abs error of each canonical tensor relative to that tensor's max magnitude.
+
+    A conv bias in front of a train-mode BatchNorm has an analytically ZERO gradient
+    (sum of BN's dx over the batch is 0): both sides then hold rounding noise (~1e-9), so
+    the scale is floored at 1e-3 of the largest gradient entry in the net."""
     out, off = {}, 0
+    floor = 1e-3 * float(np.abs(b).max())
     for name, shape, role in G.param_tensors(gene, variant, classes):
         n = int(np.prod(shape))
         ra, rb = a[off:off + n].astype(np.float64), b[off:off + n].astype(np.float64)
-        out[name] = float(np.abs(ra - rb).max() / (np.abs(rb).max() + 1e-12))
+        out[name] = float(np.abs(ra - rb).max() / max(np.abs(rb).max(), floor, 1e-30))
         off += n
     return out
 
