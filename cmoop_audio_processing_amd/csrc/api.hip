@@ -296,24 +296,43 @@ int cmoop_conv_bwd(const float* x, const float* w, const float* dy, float* dx, f
     });
 }
 
-int cmoop_conv_fwd_time(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t H, int32_t W,
-                        int32_t Cin, int32_t Cout, int32_t KS, int32_t iters, double* avg_ms) {
+int cmoop_conv_time(int32_t mode, const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t H,
+                    int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t iters, double* avg_ms) {
+    // mode 0: forward implicit GEMM; 1: dgrad implicit GEMM (y = dY [B,H,W,Cout] in, x = dX out);
+    // mode 2: wgrad MFMA kernel only (y = dY in, partials into a scratch buffer)
     return guard([&] {
         hipStream_t s = lib_stream();
-        GemmEpilogue e;
-        e.bias = bias;
         const ConvGeom g = make_geom(B, H, W, Cin, Cout, KS, 1);
-        for (int i = 0; i < 3; ++i) launch_igemm_fwd(x, w, y, g, e, s);
+        float *wd = nullptr, *wg = nullptr;
+        ConvGeom gd = g;
+        GemmEpilogue e;
+        const int S = wgrad_slices(g);
+        if (mode == 0) e.bias = bias;
+        if (mode == 1) {
+            CMOOP_HIP(hipMalloc(&wd, (size_t)g.Cout * g.K() * 4));
+            launch_flip_transpose(w, wd, Cout, KS, KS, Cin, s);
+            gd.H = g.OH; gd.W = g.OW; gd.Cin = Cout; gd.Cout = Cin; gd.OH = g.H; gd.OW = g.W;
+            gd.pad_t = KS - 1 - g.pad_t; gd.pad_l = KS - 1 - g.pad_l;
+        }
+        if (mode == 2) CMOOP_HIP(hipMalloc(&wg, (size_t)S * g.Cout * g.K() * 4));
+        auto once = [&]() {
+            if (mode == 0) launch_igemm_fwd(x, w, y, g, e, s);
+            else if (mode == 1) launch_igemm_fwd(y, wd, const_cast<float*>(x), gd, e, s);
+            else launch_igemm_wgrad(x, y, wg, g, S, s);
+        };
+        for (int i = 0; i < 3; ++i) once();
         hipEvent_t a, b;
         CMOOP_HIP(hipEventCreate(&a));
         CMOOP_HIP(hipEventCreate(&b));
         CMOOP_HIP(hipEventRecord(a, s));
-        for (int i = 0; i < iters; ++i) launch_igemm_fwd(x, w, y, g, e, s);
+        for (int i = 0; i < iters; ++i) once();
         CMOOP_HIP(hipEventRecord(b, s));
         CMOOP_HIP(hipEventSynchronize(b));
         float ms = 0.f;
         CMOOP_HIP(hipEventElapsedTime(&ms, a, b));
         hipEventDestroy(a); hipEventDestroy(b);
+        if (wd) hipFree(wd);
+        if (wg) hipFree(wg);
         *avg_ms = (double)ms / std::max(1, iters);
     });
 }

@@ -217,18 +217,39 @@ void launch_bn_bwd_reduce(const float* dY, const float* X, const float* mean, co
     CMOOP_HIP(hipGetLastError());
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ P, int blocks, int64_t M, int C,
+// Sum the per-block partials of one channel: 8 channels per 256-thread block, 32 lanes per
+// channel stride over the partial blocks, then lane 0 adds the 32 lane sums in order (fixed order
+// -> deterministic, chain length blocks/32 instead of blocks).
+__device__ __forceinline__ bool partial_sums(const float* __restrict__ P, int blocks, int C, double* s1, double* s2,
+                                             int* c_out) {
+    __shared__ double sh[2][8][32];
+    const int cl = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    const int c = blockIdx.x * 8 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int blk = lane; blk < blocks; blk += 32) {
+            a += (double)P[(size_t)blk * 2 * C + c];
+            b += (double)P[(size_t)blk * 2 * C + C + c];
+        }
+    sh[0][cl][lane] = a;
+    sh[1][cl][lane] = b;
+    __syncthreads();
+    *c_out = c;
+    if (lane != 0 || c >= C) return false;
+    a = 0.0; b = 0.0;
+    for (int l = 0; l < 32; ++l) { a += sh[0][cl][l]; b += sh[1][cl][l]; }
+    *s1 = a; *s2 = b;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ P, int blocks, int64_t M, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ mm, float* __restrict__ mv, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
                                    float eps, float momentum, float one_minus_momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < blocks; ++b) {
-        s1 += (double)P[(size_t)b * 2 * C + c];
-        s2 += (double)P[(size_t)b * 2 * C + C + c];
-    }
+    double s1, s2;
+    int c;
+    if (!partial_sums(P, blocks, C, &s1, &s2, &c)) return;
     const double mu = s1 / (double)M;
     double var = s2 / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -246,7 +267,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ P, int blocks, int6
 void launch_bn_finalize(const float* P, int blocks, int64_t M, int C, const float* gamma, const float* beta,
                         float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale, float* shift,
                         float eps, float momentum, float omm, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, P, blocks, M, C, gamma, beta, moving_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, P, blocks, M, C, gamma, beta, moving_mean,
                        moving_var, mean, invstd, scale, shift, eps, momentum, omm);
     CMOOP_HIP(hipGetLastError());
 }
@@ -298,15 +319,12 @@ void launch_scale_shift(const float* X, float* Y, const float* scale, const floa
     CMOOP_HIP(hipGetLastError());
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ P, int blocks, int C, float* __restrict__ sums,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < blocks; ++b) {
-        s1 += (double)P[(size_t)b * 2 * C + c];
-        s2 += (double)P[(size_t)b * 2 * C + C + c];
-    }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ P, int blocks, int C,
+                                                              float* __restrict__ sums, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+    double s1, s2;
+    int c;
+    if (!partial_sums(P, blocks, C, &s1, &s2, &c)) return;
     sums[c] = (float)s1;
     sums[C + c] = (float)s2;
     dbeta[c] = (float)s1;
@@ -345,7 +363,7 @@ void launch_bn_bwd_apply(const float* dY, const float* X, const float* mean, con
                          int mask_x_pos, hipStream_t s) {
     // sums live right after the partials (caller reserves 2*C floats there)
     float* sums = const_cast<float*>(P) + (size_t)blocks * 2 * C;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, P, blocks, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, P, blocks, C, sums, dgamma, dbeta);
     CMOOP_HIP(hipGetLastError());
     const int64_t n4 = M * C / 4;
     if (n4 == 0) return;
@@ -354,16 +372,16 @@ void launch_bn_bwd_apply(const float* dY, const float* X, const float* mean, con
     CMOOP_HIP(hipGetLastError());
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ P, int blocks, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0;
-    for (int b = 0; b < blocks; ++b) s1 += (double)P[(size_t)b * 2 * C + c];
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ P, int blocks, int C,
+                                                              float* __restrict__ out) {
+    double s1, s2;
+    int c;
+    if (!partial_sums(P, blocks, C, &s1, &s2, &c)) return;
     out[c] = (float)s1;
 }
 
 void launch_colsum_finalize(const float* P, int blocks, int C, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, P, blocks, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, P, blocks, C, out);
     CMOOP_HIP(hipGetLastError());
 }
 

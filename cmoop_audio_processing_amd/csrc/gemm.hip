@@ -7,6 +7,7 @@
 // k = 16*kk + 4*q + j for the j-th of four MFMAs (A and B use the same k assignment,
 // so the order of summation inside a 16-k group is a fixed permutation).
 #include "kernels.h"
+#include <hip/hip_ext.h>
 
 namespace cmoop {
 
@@ -38,18 +39,21 @@ static GeomDev to_dev(const ConvGeom& g) {
 
 // ---------------------------------------------------------------------------
 // forward-type kernel: Y[M][N] = im2col(X)[M][K] * Wt[N][K]^T
-// block = 256 threads = 4 waves; tile 128 (M) x BN; wave w owns rows 32w..32w+31.
+// block = 256 threads = 4 waves laid out WM x WN over a BM x BN tile; each wave owns
+// RT x CT MFMA tiles of 16x16.  Tile shape is picked per layer so that the grid
+// fills the 256 CUs (small-spatial deep layers use 64-row tiles).
 // ---------------------------------------------------------------------------
-template <int BN, int BK>
+template <int BM, int BN, int BK, int WM>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                         float* __restrict__ Y, GeomDev g, EpiDev e) {
-    constexpr int BM = 128;
+    constexpr int WN = 4 / WM;
     constexpr int LDK = BK + 4;
     constexpr int TPR = BK / 4;
     constexpr int RPP = 256 / TPR;
-    constexpr int APASS = BM / RPP;
+    constexpr int APASS = (BM + RPP - 1) / RPP;
     constexpr int BPASS = (BN + RPP - 1) / RPP;
-    constexpr int NT = BN / 16;
+    constexpr int RT = BM / WM / 16, CT = BN / WN / 16;
+    static_assert(RT >= 1 && CT >= 1, "tile too small for the wave layout");
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
 
@@ -63,8 +67,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     bool a_ok[APASS];
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
-        int m = m0 + lrow + p * RPP;
-        a_ok[p] = m < g.M;
+        int ml = lrow + p * RPP;
+        int m = m0 + ml;
+        a_ok[p] = ml < BM && m < g.M;
         int mm = a_ok[p] ? m : 0;
         int b = mm / g.OHW, r = mm - b * g.OHW;
         int oh = r / g.OW, ow = r - oh * g.OW;
@@ -98,8 +103,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < APASS; ++p)
-            *reinterpret_cast<f32x4*>(&As[buf][(lrow + p * RPP) * LDK + 4 * kq]) = ra[p];
+        for (int p = 0; p < APASS; ++p) {
+            int ml = lrow + p * RPP;
+            if (ml < BM) *reinterpret_cast<f32x4*>(&As[buf][ml * LDK + 4 * kq]) = ra[p];
+        }
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             int nl = lrow + p * RPP;
@@ -108,11 +115,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     };
 
     const int wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
-    f32x4 acc[2][NT];
+    const int wrow = (wave / WN) * (BM / WM), wcol = (wave % WN) * (BN / WN);
+    f32x4 acc[RT][CT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = (g.K + BK - 1) / BK;
     load_chunk(0);
@@ -123,19 +131,19 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         if (c + 1 < nchunks) load_chunk(c + 1);
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            f32x4 a[2], b[NT];
+            f32x4 a[RT], b[CT];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                a[rt] = *reinterpret_cast<const f32x4*>(&As[buf][(wave * 32 + rt * 16 + lr) * LDK + kk * 16 + q * 4]);
+            for (int rt = 0; rt < RT; ++rt)
+                a[rt] = *reinterpret_cast<const f32x4*>(&As[buf][(wrow + rt * 16 + lr) * LDK + kk * 16 + q * 4]);
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct)
-                b[ct] = *reinterpret_cast<const f32x4*>(&Bs[buf][(ct * 16 + lr) * LDK + kk * 16 + q * 4]);
+            for (int ct = 0; ct < CT; ++ct)
+                b[ct] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wcol + ct * 16 + lr) * LDK + kk * 16 + q * 4]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < NT; ++ct)
+                    for (int ct = 0; ct < CT; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][j], b[ct][j], acc[rt][ct], 0, 0, 0);
         }
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
@@ -145,10 +153,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     // epilogue: C/D map of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg
     const int N = g.Cout;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wave * 32 + rt * 16 + q * 4 + r;
+            const int row = m0 + wrow + rt * 16 + q * 4 + r;
             if (row >= g.M) continue;
             size_t rbase;
             if (e.out_stride == 1) {
@@ -159,8 +167,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
                 rbase = ((size_t)(b * e.OHf + oh * e.out_stride) * e.OWf + ow * e.out_stride) * N;
             }
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
-                const int col = n0 + ct * 16 + lr;
+            for (int ct = 0; ct < CT; ++ct) {
+                const int col = n0 + wcol + ct * 16 + lr;
                 if (col >= N) continue;
                 float v = acc[rt][ct][r];
                 if (e.bias) v += e.bias[col];
@@ -178,15 +186,29 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     }
 }
 
-template <int BN, int BK>
-static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDev& g, const EpiDev& e, hipStream_t s) {
-    dim3 grid(cdiv(g.M, 128), cdiv(g.Cout, BN));
-    hipLaunchKernelGGL((igemm_fwd_kernel<BN, BK>), grid, dim3(256), 0, s, X, Wt, Y, g, e);
+template <int BM, int BN, int BK, int WM>
+static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDev& g, const EpiDev& e, hipStream_t s,
+                         const GemmTiming* tm) {
+    dim3 grid(cdiv(g.M, BM), cdiv(g.Cout, BN));
+    if (tm && tm->start)
+        hipExtLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, Wt, Y, g, e);
+    else
+        hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM>), grid, dim3(256), 0, s, X, Wt, Y, g, e);
     CMOOP_HIP(hipGetLastError());
 }
 
+// tile choice: the largest tile whose grid still covers the chip (>= 1.5 blocks per CU), else the smallest
+static void pick_tile(int M, int N, int* bm, int* bn) {
+    const int bn_small = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+    int cand[3][2] = {{128, N > 64 ? 128 : bn_small}, {128, bn_small}, {64, bn_small}};
+    for (int i = 0; i < 3; ++i) {
+        const long blocks = (long)cdiv(M, cand[i][0]) * cdiv(N, cand[i][1]);
+        if (blocks >= 384 || i == 2) { *bm = cand[i][0]; *bn = cand[i][1]; return; }
+    }
+}
+
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& cg, const GemmEpilogue& ep,
-                     hipStream_t s) {
+                     hipStream_t s, const GemmTiming* tm) {
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
     EpiDev e;
@@ -196,18 +218,25 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     if (e.out_stride > 1)
         CMOOP_REQUIRE((int64_t)g.B * e.OHf * e.OWf * g.Cout < (1ll << 31), "scattered output too large");
     const bool bk32 = (g.Cin % 32 == 0);
-    const int N = g.Cout;
-#define CMOOP_FWD(BN_)                                                        \
-    do {                                                                      \
-        if (bk32) launch_fwd_t<BN_, 32>(X, Wt, Y, g, e, s);                   \
-        else launch_fwd_t<BN_, 16>(X, Wt, Y, g, e, s);                        \
+    int bm, bn;
+    pick_tile(g.M, g.Cout, &bm, &bn);
+#define CMOOP_FWD(BM_, BN_, WM_)                                                   \
+    do {                                                                           \
+        if (bk32) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm);          \
+        else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm);               \
     } while (0)
-    if (N <= 16) CMOOP_FWD(16);
-    else if (N <= 32) CMOOP_FWD(32);
-    else if (N <= 64) CMOOP_FWD(64);
-    else CMOOP_FWD(128);
+    if (bm == 128) {
+        if (bn == 128) CMOOP_FWD(128, 128, 2);
+        else if (bn == 64) CMOOP_FWD(128, 64, 4);
+        else if (bn == 32) CMOOP_FWD(128, 32, 4);
+        else CMOOP_FWD(128, 16, 4);
+    } else {
+        if (bn == 64) CMOOP_FWD(64, 64, 2);
+        else if (bn == 32) CMOOP_FWD(64, 32, 4);
+        else CMOOP_FWD(64, 16, 4);
+    }
 #undef CMOOP_FWD
-    return (N <= 16 ? 16 : N <= 32 ? 32 : N <= 64 ? 64 : 128) * 100 + (bk32 ? 32 : 16);
+    return bm * 100000 + bn * 100 + (bk32 ? 32 : 16);
 }
 
 // ---------------------------------------------------------------------------
@@ -337,7 +366,8 @@ int wgrad_slices(const ConvGeom& g) {
     return S;
 }
 
-int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s) {
+int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s,
+                       const GemmTiming* tm) {
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
     int rps = cdiv(g.M, S);
@@ -345,25 +375,38 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     const int N = g.Cout;
     const int bco = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
     dim3 grid(cdiv(g.K, 64), cdiv(N, bco), S);
-    if (bco == 16) hipLaunchKernelGGL((igemm_wgrad_kernel<16>), grid, dim3(256), 0, s, X, dY, P, g, rps);
-    else if (bco == 32) hipLaunchKernelGGL((igemm_wgrad_kernel<32>), grid, dim3(256), 0, s, X, dY, P, g, rps);
-    else hipLaunchKernelGGL((igemm_wgrad_kernel<64>), grid, dim3(256), 0, s, X, dY, P, g, rps);
+#define CMOOP_WG(BCO_)                                                                                          \
+    do {                                                                                                       \
+        if (tm && tm->start)                                                                                   \
+            hipExtLaunchKernelGGL((igemm_wgrad_kernel<BCO_>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((igemm_wgrad_kernel<BCO_>), grid, dim3(256), 0, s, X, dY, P, g, rps);             \
+    } while (0)
+    if (bco == 16) CMOOP_WG(16);
+    else if (bco == 32) CMOOP_WG(32);
+    else CMOOP_WG(64);
+#undef CMOOP_WG
     CMOOP_HIP(hipGetLastError());
     return bco;
 }
 
+// out[i] = sum_s P[s][i]: 64 elements x 4 slice lanes per block, fixed summation order
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ P, float* __restrict__ out, int S,
                                                             int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + e;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += P[(size_t)s * n + i];
-    out[i] = acc;
+    if (i < n)
+        for (int s = sl; s < S; s += 4) acc += P[(size_t)s * n + i];
+    red[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && i < n) out[i] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
 }
 
 void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, P, out, S, n);
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, P, out, S, n);
     CMOOP_HIP(hipGetLastError());
 }
 

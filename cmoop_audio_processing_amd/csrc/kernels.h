@@ -34,14 +34,19 @@ struct GemmEpilogue {
 };
 
 // Y[m][n] = sum_k im2col(X)[m][k] * Wt[n][k]  (+ epilogue).  Cin must be a power of two >= 16.
-// returns the instantiation code BN*100+BK of the kernel that was launched
+// optional start/stop events filled with the kernel's own begin/end (hipExtLaunchKernelGGL)
+struct GemmTiming {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+// returns the instantiation code BM*100000 + BN*100 + BK of the kernel that was launched
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& g,
-                     const GemmEpilogue& e, hipStream_t s);
+                     const GemmEpilogue& e, hipStream_t s, const GemmTiming* tm = nullptr);
 
 // dWt[n][k] = sum_m dY[m][n] * im2col(X)[m][k], split over S row-slices into P[S][N][K].
 int wgrad_slices(const ConvGeom& g);
 // returns the instantiation code BCO of the kernel that was launched
-int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& g, int S, hipStream_t s);
+int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& g, int S, hipStream_t s,
+                       const GemmTiming* tm = nullptr);
 // out[i] = sum_s P[s][i]  (fixed order -> deterministic)
 void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s);
 // Wd[ci][KH-1-kh][KW-1-kw][co] = W[co][kh][kw][ci]   (operand of the dgrad implicit GEMM)

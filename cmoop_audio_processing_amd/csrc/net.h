@@ -40,8 +40,8 @@ struct ProfileTotals {   // keyed by kernel instantiation name, e.g. "igemm_fwd_
 ProfileTotals& profile_totals();
 
 struct GemmHook {   // brackets every MFMA GEMM launch (HIP-event sampling)
-    virtual void before(int cls, double flops) = 0;
-    virtual void after(int code) = 0;
+    virtual const GemmTiming* begin(int cls, double flops) = 0;   // null: do not time this launch
+    virtual void end(int code) = 0;
     virtual ~GemmHook() {}
 };
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
@@ -79,8 +79,8 @@ struct Op {
 
 class Net : public GemmHook {
   public:
-    void before(int cls, double flops) override;
-    void after(int code) override;
+    const GemmTiming* begin(int cls, double flops) override;
+    void end(int code) override;
     Net(const int32_t gene[6], const NetConfig& cfg, int T, int F, uint32_t seed, hipStream_t stream);
     ~Net();
     Net(const Net&) = delete;
@@ -127,7 +127,7 @@ class Net : public GemmHook {
     int logits_ = -1;
     long long step_ = 0, iterations_ = 0;
     bool profiling_now_ = false, hook_live_ = false;
-    struct EvPair { hipEvent_t a, b; double flops; int cls, code; };
+    struct EvPair { GemmTiming t; double flops; int cls, code; };
     std::vector<EvPair> ev_pool_;
     size_t ev_used_ = 0;
 };

@@ -100,7 +100,7 @@ Net::Net(const int32_t gene[6], const NetConfig& cfg, int T, int F, uint32_t see
 }
 
 Net::~Net() {
-    for (auto& e : ev_pool_) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto& e : ev_pool_) { hipEventDestroy(e.t.start); hipEventDestroy(e.t.stop); }
     for (void* p : allocs_) hipFree(p);
 }
 
@@ -279,7 +279,7 @@ void Net::build_plan() {
     CMOOP_HIP(hipMemsetAsync(acc_train_, 0, 32, stream_));
     if (cfg_.profile_every > 0) {
         ev_pool_.resize(1024);
-        for (auto& e : ev_pool_) { CMOOP_HIP(hipEventCreate(&e.a)); CMOOP_HIP(hipEventCreate(&e.b)); }
+        for (auto& e : ev_pool_) { CMOOP_HIP(hipEventCreate(&e.t.start)); CMOOP_HIP(hipEventCreate(&e.t.stop)); }
     }
 }
 
@@ -315,16 +315,15 @@ void Net::restore_snapshot() {
     if (snap_) CMOOP_HIP(hipMemcpyAsync(params_, snap_, n_params_ * 4, hipMemcpyDeviceToDevice, stream_));
 }
 
-void Net::before(int cls, double flops) {
+const GemmTiming* Net::begin(int cls, double flops) {
     hook_live_ = profiling_now_ && ev_used_ < ev_pool_.size();
-    if (!hook_live_) return;
-    CMOOP_HIP(hipEventRecord(ev_pool_[ev_used_].a, stream_));
+    if (!hook_live_) return nullptr;
     ev_pool_[ev_used_].flops = flops;
     ev_pool_[ev_used_].cls = cls;
+    return &ev_pool_[ev_used_].t;
 }
-void Net::after(int code) {
+void Net::end(int code) {
     if (!hook_live_) return;
-    CMOOP_HIP(hipEventRecord(ev_pool_[ev_used_].b, stream_));
     ev_pool_[ev_used_].code = code;
     ++ev_used_;
     hook_live_ = false;
@@ -335,9 +334,9 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
                            float* red_ws, hipStream_t s, GemmHook* hook) {
     const int M = g.M(), N = g.Cout, K = g.K();
     const int S = wgrad_slices(g);
-    if (hook) hook->before(1, 2.0 * M * (double)N * K);
-    const int code = launch_igemm_wgrad(X, dY, wgrad_ws, g, S, s);
-    if (hook) hook->after(code);
+    const GemmTiming* tm = hook ? hook->begin(1, 2.0 * M * (double)N * K) : nullptr;
+    const int code = launch_igemm_wgrad(X, dY, wgrad_ws, g, S, s, tm);
+    if (hook) hook->end(code);
     launch_reduce_slices(wgrad_ws, dW, S, (int64_t)N * K, s);
     if (N % 4 == 0) {
         const int nb = colreduce_blocks(M, N);
@@ -374,14 +373,14 @@ void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGe
     e.accumulate = accumulate;
     e.mask = mask;
     e.mask_scale = mask_scale;
-    if (hook) hook->before(0, 2.0 * gd.M() * (double)gd.Cout * gd.K());
-    const int code = launch_igemm_fwd(dY, wd_ws, dX, gd, e, s);
-    if (hook) hook->after(code);
+    const GemmTiming* tm = hook ? hook->begin(0, 2.0 * gd.M() * (double)gd.Cout * gd.K()) : nullptr;
+    const int code = launch_igemm_fwd(dY, wd_ws, dX, gd, e, s, tm);
+    if (hook) hook->end(code);
 }
 
 void Net::run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e) {
-    before(cls, 2.0 * g.M() * (double)g.Cout * g.K());
-    after(launch_igemm_fwd(X, Wt, Y, g, e, stream_));
+    const GemmTiming* tm = begin(cls, 2.0 * g.M() * (double)g.Cout * g.K());
+    end(launch_igemm_fwd(X, Wt, Y, g, e, stream_, tm));
 }
 
 void Net::drain_profile() {
@@ -390,10 +389,13 @@ void Net::drain_profile() {
     std::lock_guard<std::mutex> l(t.mu);
     for (size_t i = 0; i < ev_used_; ++i) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, ev_pool_[i].t.start, ev_pool_[i].t.stop) == hipSuccess) {
             const int code = ev_pool_[i].code;
+            const int bm = code / 100000, bn = (code / 100) % 1000, bk = code % 100;
+            const int wm = (bm == bn) ? 2 : 4;   // wave layout of each instantiation (gemm.hip)
             const std::string name = ev_pool_[i].cls == 0
-                ? "igemm_fwd_kernel<" + std::to_string(code / 100) + "," + std::to_string(code % 100) + ">"
+                ? "igemm_fwd_kernel<" + std::to_string(bm) + ", " + std::to_string(bn) + ", " + std::to_string(bk) + ", " +
+                      std::to_string(wm) + ">"
                 : "igemm_wgrad_kernel<" + std::to_string(code) + ">";
             ProfileEntry& e = t.by_kernel[name];
             e.ms += ms;

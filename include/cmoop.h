@@ -124,9 +124,10 @@ int cmoop_conv_fwd(const float* x_dev, const float* w_dev, const float* bias_dev
 /* dx = dgrad(dy) (optionally masked by x > 0), dw[Cout][KS][KS][Cin], db[Cout] */
 int cmoop_conv_bwd(const float* x_dev, const float* w_dev, const float* dy_dev, float* dx_dev, float* dw_dev, float* db_dev,
                    int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t mask_relu);
-/* average ms per launch of the forward implicit GEMM over `iters` launches (HIP events on the library stream) */
-int cmoop_conv_fwd_time(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int32_t B, int32_t H,
-                        int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t iters, double* avg_ms);
+/* average ms per launch over `iters` back-to-back launches (HIP events on the library stream);
+ * mode 0: forward implicit GEMM, 1: dgrad implicit GEMM (y holds dY, x receives dX), 2: wgrad MFMA kernel */
+int cmoop_conv_time(int32_t mode, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int32_t B,
+                    int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t iters, double* avg_ms);
 int cmoop_maxpool_fwd(const float* x_dev, float* y_dev, uint8_t* arg_dev, int32_t B, int32_t H, int32_t W, int32_t C);
 int cmoop_maxpool_bwd(const float* dy_dev, const uint8_t* arg_dev, const float* y_dev, float* dx_dev, int32_t B, int32_t H,
                       int32_t W, int32_t C, int32_t mask_y_pos);
