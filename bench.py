@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--pop", type=int, default=40)
     ap.add_argument("--clips", type=int, default=30000, help="synthetic clips (80/10/10 split)")
-    ap.add_argument("--epochs", type=int, default=10, help="fixed epoch budget per candidate (BASELINE.md §3)")
+    ap.add_argument("--epochs", type=int, default=2, help="fixed epoch budget per candidate; 10 = full SURVEY §8d protocol")
     ap.add_argument("--variant", default="A")
     ap.add_argument("--classes", type=int, default=10)
     ap.add_argument("--slots", type=int, default=4)
@@ -161,6 +161,16 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    # heartbeat on stderr (stdout carries only the JSON line): long steps must not look hung
+    import threading
+    stop_hb = threading.Event()
+
+    def heartbeat():
+        t_hb = time.perf_counter()
+        while not stop_hb.wait(60.0):
+            print(f"[bench rank {rank}] running, {time.perf_counter() - t_hb:.0f} s", file=sys.stderr, flush=True)
+    threading.Thread(target=heartbeat, daemon=True).start()
 
     for _ in range(args.warmup):
         ev.compute_objectives_and_constraints(pop)

@@ -253,7 +253,13 @@ int cmoop_conv_fwd(const float* x, const float* w, const float* bias, float* y, 
         } else {
             GemmEpilogue e;
             e.bias = bias; e.relu = relu;
-            launch_igemm_fwd(x, w, y, make_geom(B, H, W, Cin, Cout, KS, stride), e, s);
+            const ConvGeom g = make_geom(B, H, W, Cin, Cout, KS, stride);
+            const size_t skf = igemm_splitk_workspace(g);
+            float* sk = nullptr;
+            if (skf) CMOOP_HIP(hipMalloc(&sk, skf * 4));
+            launch_igemm_fwd(x, w, y, g, e, s, nullptr, sk, skf);
+            CMOOP_HIP(hipStreamSynchronize(s));
+            if (sk) hipFree(sk);
         }
         CMOOP_HIP(hipStreamSynchronize(s));
     });
@@ -278,7 +284,7 @@ int cmoop_conv_bwd(const float* x, const float* w, const float* dy, float* dx, f
             return;
         }
         const ConvGeom g = make_geom(B, H, W, Cin, Cout, KS, stride);
-        float *wg = nullptr, *red = nullptr, *wd = nullptr;
+        float *wg = nullptr, *red = nullptr, *wd = nullptr, *sk = nullptr;
         CMOOP_HIP(hipMalloc(&wg, (size_t)wgrad_slices(g) * g.Cout * g.K() * 4));
         CMOOP_HIP(hipMalloc(&red, ((size_t)1024 * 2 * Cout + 2 * Cout + 64) * 4));
         CMOOP_HIP(hipMalloc(&wd, (size_t)g.Cout * g.K() * 4));
@@ -289,10 +295,15 @@ int cmoop_conv_bwd(const float* x, const float* w, const float* dy, float* dx, f
                 CMOOP_HIP(hipMemsetAsync(dx, 0, (size_t)B * H * W * Cin * 4, s));
                 accumulate = 1;
             }
-            conv_backward_data(dy, w, dx, g, wd, mask_relu ? x : nullptr, 1.f, accumulate, s, nullptr);
+            ConvGeom gd = g;
+            gd.H = g.OH; gd.W = g.OW; gd.Cin = g.Cout; gd.Cout = g.Cin; gd.OH = g.H; gd.OW = g.W;
+            const size_t skf = (stride == 1 && Cout >= 16 && (Cout & (Cout - 1)) == 0) ? igemm_splitk_workspace(gd) : 0;
+            if (skf) CMOOP_HIP(hipMalloc(&sk, skf * 4));
+            conv_backward_data(dy, w, dx, g, wd, mask_relu ? x : nullptr, 1.f, accumulate, s, nullptr, sk, skf);
         }
         CMOOP_HIP(hipStreamSynchronize(s));
         hipFree(wg); hipFree(red); hipFree(wd);
+        if (sk) hipFree(sk);
     });
 }
 
@@ -303,7 +314,7 @@ int cmoop_conv_time(int32_t mode, const float* x, const float* w, const float* b
     return guard([&] {
         hipStream_t s = lib_stream();
         const ConvGeom g = make_geom(B, H, W, Cin, Cout, KS, 1);
-        float *wd = nullptr, *wg = nullptr;
+        float *wd = nullptr, *wg = nullptr, *sk = nullptr;
         ConvGeom gd = g;
         GemmEpilogue e;
         const int S = wgrad_slices(g);
@@ -315,9 +326,11 @@ int cmoop_conv_time(int32_t mode, const float* x, const float* w, const float* b
             gd.pad_t = KS - 1 - g.pad_t; gd.pad_l = KS - 1 - g.pad_l;
         }
         if (mode == 2) CMOOP_HIP(hipMalloc(&wg, (size_t)S * g.Cout * g.K() * 4));
+        const size_t skf = mode == 0 ? igemm_splitk_workspace(g) : (mode == 1 ? igemm_splitk_workspace(gd) : 0);
+        if (skf) CMOOP_HIP(hipMalloc(&sk, skf * 4));
         auto once = [&]() {
-            if (mode == 0) launch_igemm_fwd(x, w, y, g, e, s);
-            else if (mode == 1) launch_igemm_fwd(y, wd, const_cast<float*>(x), gd, e, s);
+            if (mode == 0) launch_igemm_fwd(x, w, y, g, e, s, nullptr, sk, skf);
+            else if (mode == 1) launch_igemm_fwd(y, wd, const_cast<float*>(x), gd, e, s, nullptr, sk, skf);
             else launch_igemm_wgrad(x, y, wg, g, S, s);
         };
         for (int i = 0; i < 3; ++i) once();
@@ -333,6 +346,7 @@ int cmoop_conv_time(int32_t mode, const float* x, const float* w, const float* b
         hipEventDestroy(a); hipEventDestroy(b);
         if (wd) hipFree(wd);
         if (wg) hipFree(wg);
+        if (sk) hipFree(sk);
         *avg_ms = (double)ms / std::max(1, iters);
     });
 }

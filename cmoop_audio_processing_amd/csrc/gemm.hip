@@ -45,7 +45,8 @@ static GeomDev to_dev(const ConvGeom& g) {
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int BK, int WM>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
-                                                        float* __restrict__ Y, GeomDev g, EpiDev e) {
+                                                        float* __restrict__ Y, GeomDev g, EpiDev e,
+                                                        float* __restrict__ slab, int chunks_per_split) {
     constexpr int WN = 4 / WM;
     constexpr int LDK = BK + 4;
     constexpr int TPR = BK / 4;
@@ -78,8 +79,11 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         a_base[p] = b * g.H * g.W;
     }
 
-    f32x4 ra[APASS], rb[BPASS];
-    auto load_chunk = [&](int c) {
+    // two register sets: the loads of chunk c+2 are issued before chunk c is computed and are
+    // written to LDS only after chunk c+1's compute, so a global-load round trip has two MFMA
+    // phases to land (the 64-row tiles of the deep layers have only ~1k MFMA cycles per phase)
+    f32x4 ra0[APASS], rb0[BPASS], ra1[BM <= 64 ? APASS : 1], rb1[BM <= 64 ? BPASS : 1];
+    auto load_chunk = [&](int c, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
         const int kidx = c * BK + 4 * kq;
         const bool kok = kidx < g.K;
         const int tap = kidx >> g.cshift, ci = kidx & (g.Cin - 1);
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             rb[p] = v;
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
             int ml = lrow + p * RPP;
@@ -122,13 +126,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nchunks = (g.K + BK - 1) / BK;
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load_chunk(c + 1);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             f32x4 a[RT], b[CT];
@@ -146,12 +144,62 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
                     for (int ct = 0; ct < CT; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][j], b[ct][j], acc[rt][ct], 0, 0, 0);
         }
-        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    };
+
+    // split-K: blockIdx.z owns K chunks [cbeg, nchunks) and writes raw partial sums to its slab
+    const int cbeg = blockIdx.z * chunks_per_split;
+    const int nchunks = min((g.K + BK - 1) / BK, cbeg + chunks_per_split);
+    if constexpr (BM <= 64) {
+        // distance-2 prefetch (two register sets) for the small tiles of the deep layers
+        load_chunk(cbeg, ra0, rb0);
+        store_chunk(0, ra0, rb0);
+        if (cbeg + 1 < nchunks) load_chunk(cbeg + 1, ra1, rb1);
         __syncthreads();
+        for (int c = cbeg; c < nchunks; c += 2) {
+            // even chunk c lives in LDS[0]; set 1 holds chunk c+1; set 0 is free
+            if (c + 2 < nchunks) load_chunk(c + 2, ra0, rb0);
+            compute(0);
+            if (c + 1 < nchunks) store_chunk(1, ra1, rb1);
+            __syncthreads();
+            if (c + 1 >= nchunks) break;
+            // odd chunk c+1 lives in LDS[1]; set 0 holds chunk c+2; set 1 is free
+            if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
+            compute(1);
+            if (c + 2 < nchunks) store_chunk(0, ra0, rb0);
+            __syncthreads();
+        }
+    } else {
+        // distance-1 prefetch: one register set keeps the 128-row tiles at two workgroups per CU
+        load_chunk(cbeg, ra0, rb0);
+        store_chunk(0, ra0, rb0);
+        __syncthreads();
+        for (int c = cbeg; c < nchunks; ++c) {
+            const int buf = (c - cbeg) & 1;
+            if (c + 1 < nchunks) load_chunk(c + 1, ra0, rb0);
+            compute(buf);
+            if (c + 1 < nchunks) store_chunk(buf ^ 1, ra0, rb0);
+            __syncthreads();
+        }
     }
 
     // epilogue: C/D map of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg
     const int N = g.Cout;
+    if (slab) {   // split-K partial: raw sums, the combine kernel applies the epilogue
+        float* Pz = slab + (size_t)blockIdx.z * g.M * N;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wrow + rt * 16 + q * 4 + r;
+                if (row >= g.M) continue;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int col = n0 + wcol + ct * 16 + lr;
+                    if (col < N) Pz[(size_t)row * N + col] = acc[rt][ct][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -186,29 +234,92 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     }
 }
 
-template <int BM, int BN, int BK, int WM>
-static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDev& g, const EpiDev& e, hipStream_t s,
-                         const GemmTiming* tm) {
-    dim3 grid(cdiv(g.M, BM), cdiv(g.Cout, BN));
-    if (tm && tm->start)
-        hipExtLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, Wt, Y, g, e);
-    else
-        hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM>), grid, dim3(256), 0, s, X, Wt, Y, g, e);
-    CMOOP_HIP(hipGetLastError());
-}
-
-// tile choice: the largest tile whose grid still covers the chip (>= 1.5 blocks per CU), else the smallest
-static void pick_tile(int M, int N, int* bm, int* bn) {
-    const int bn_small = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
-    int cand[3][2] = {{128, N > 64 ? 128 : bn_small}, {128, bn_small}, {64, bn_small}};
-    for (int i = 0; i < 3; ++i) {
-        const long blocks = (long)cdiv(M, cand[i][0]) * cdiv(N, cand[i][1]);
-        if (blocks >= 384 || i == 2) { *bm = cand[i][0]; *bn = cand[i][1]; return; }
+// combine the split-K slabs in fixed order and apply the epilogue
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ P, float* __restrict__ Y, GeomDev g,
+                                                             EpiDev e, int splits) {
+    const int N = g.Cout;
+    const size_t total = (size_t)g.M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int row = (int)(i / N), col = (int)(i - (size_t)row * N);
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += P[(size_t)z * total + i];
+        if (e.bias) v += e.bias[col];
+        if (e.relu) v = fmaxf(v, 0.f);
+        size_t off = i;
+        if (e.out_stride != 1) {
+            int b = row / g.OHW, rr = row - b * g.OHW;
+            int oh = rr / g.OW, ow = rr - oh * g.OW;
+            off = ((size_t)(b * e.OHf + oh * e.out_stride) * e.OWf + ow * e.out_stride) * N + col;
+        }
+        if (e.dropout) {
+            uint32_t u24 = fmix32(e.drop_prefix ^ (uint32_t)i) >> 8;
+            v = (u24 >= e.drop_thr) ? v * e.drop_scale : 0.f;
+        }
+        if (e.mask) v = (e.mask[off] > 0.f) ? v * e.mask_scale : 0.f;
+        if (e.accumulate) v += Y[off];
+        Y[off] = v;
     }
 }
 
+template <int BM, int BN, int BK, int WM>
+static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDev& g, const EpiDev& e, hipStream_t s,
+                         const GemmTiming* tm, float* slab, int splits) {
+    dim3 grid(cdiv(g.M, BM), cdiv(g.Cout, BN), splits);
+    const int nchunks = cdiv(g.K, BK);
+    const int cps = cdiv(nchunks, splits);
+    float* sl = splits > 1 ? slab : nullptr;
+    if (tm && tm->start)
+        hipExtLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, Wt, Y, g, e,
+                              sl, cps);
+    else
+        hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM>), grid, dim3(256), 0, s, X, Wt, Y, g, e, sl, cps);
+    CMOOP_HIP(hipGetLastError());
+    if (splits > 1) {
+        const size_t total = (size_t)g.M * g.Cout;
+        const unsigned gridc = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(splitk_combine_kernel, dim3(gridc), dim3(256), 0, s, slab, Y, g, e, splits);
+        CMOOP_HIP(hipGetLastError());
+    }
+}
+
+// Tile / split choice.  Prefer the big (most efficient) tile; if its grid does not cover the chip
+// (deep layers: 13x5 or 26x10 pixels x 64 samples) split the long K axis across blockIdx.z when a
+// slab workspace is available, else fall back to 64-row tiles.
+static void pick_tile(int M, int N, int K, int bk, size_t ws_floats, int* bm, int* bn, int* splits) {
+    const int bn_small = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+    const int bn_big = N > 64 ? 128 : bn_small;
+    *splits = 1;
+    long blocks = (long)cdiv(M, 128) * cdiv(N, bn_big);
+    if (blocks >= 384) { *bm = 128; *bn = bn_big; return; }
+    const int nchunks = cdiv(K, bk);
+    if (nchunks >= 16 && ws_floats > 0) {
+        int sp = (int)std::min<long>(cdiv(768, (int)blocks), nchunks / 8);
+        sp = std::min(sp, 32);
+        while (sp > 1 && (size_t)sp * M * N > ws_floats) --sp;
+        if (sp > 1) {
+            const int cps = cdiv(nchunks, sp);
+            sp = cdiv(nchunks, cps);          // no empty split
+            *bm = 128; *bn = bn_big; *splits = sp;
+            return;
+        }
+    }
+    blocks = (long)cdiv(M, 128) * cdiv(N, bn_small);
+    if (blocks >= 384) { *bm = 128; *bn = bn_small; return; }
+    *bm = 64; *bn = bn_small;
+}
+
+size_t igemm_splitk_workspace(const ConvGeom& g) {
+    // upper bound of what pick_tile may ask for: splits * M * N with splits <= 768 / blocks + 1
+    const int M = g.M(), N = g.Cout;
+    const int bn_big = N > 64 ? 128 : (N <= 16 ? 16 : (N <= 32 ? 32 : 64));
+    const long blocks = (long)cdiv(M, 128) * cdiv(N, bn_big);
+    if (blocks >= 384) return 0;
+    const int sp = std::min(32, cdiv(768, (int)blocks));
+    return (size_t)sp * M * N;
+}
+
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& cg, const GemmEpilogue& ep,
-                     hipStream_t s, const GemmTiming* tm) {
+                     hipStream_t s, const GemmTiming* tm, float* splitk_ws, size_t splitk_ws_floats) {
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
     EpiDev e;
@@ -218,12 +329,12 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     if (e.out_stride > 1)
         CMOOP_REQUIRE((int64_t)g.B * e.OHf * e.OWf * g.Cout < (1ll << 31), "scattered output too large");
     const bool bk32 = (g.Cin % 32 == 0);
-    int bm, bn;
-    pick_tile(g.M, g.Cout, &bm, &bn);
-#define CMOOP_FWD(BM_, BN_, WM_)                                                   \
-    do {                                                                           \
-        if (bk32) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm);          \
-        else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm);               \
+    int bm, bn, splits;
+    pick_tile(g.M, g.Cout, g.K, bk32 ? 32 : 16, splitk_ws ? splitk_ws_floats : 0, &bm, &bn, &splits);
+#define CMOOP_FWD(BM_, BN_, WM_)                                                              \
+    do {                                                                                      \
+        if (bk32) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);   \
+        else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);        \
     } while (0)
     if (bm == 128) {
         if (bn == 128) CMOOP_FWD(128, 128, 2);
@@ -245,14 +356,15 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
 // m-major (ds_read_b32, leading dimension == 16 mod 32 -> conflict-free).
 // grid = (K tiles of 64, N tiles of BCO, S row-slices); partials P[S][N][K].
 // ---------------------------------------------------------------------------
-template <int BCO>
+template <int BCO, int BKI>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                           float* __restrict__ P, GeomDev g, int rows_per_slice) {
-    constexpr int MC = 32, BKI = 64;
-    constexpr int LDX = BKI + 16;
+    constexpr int MC = 32;
+    constexpr int LDX = BKI + 16;                          // == 16 mod 32
     constexpr int LDY = (BCO == 16) ? 16 : BCO + 16;
-    constexpr int CT = BCO / 16;      // co tiles
-    constexpr int KPW = CT;           // k tiles per wave (4 k tiles / (4 / CT) wave groups)
+    constexpr int CT = BCO / 16, KT = BKI / 16;             // co tiles, k tiles of the block
+    constexpr int KPW = KT * CT / 4;                        // k tiles per wave
+    constexpr int TPRX = BKI / 4, RPPX = 256 / TPRX, XPASS = MC / RPPX;
     constexpr int TPRY = BCO / 4, RPPY = 256 / TPRY;
     constexpr int YPASS = (MC + RPPY - 1) / RPPY;
     __shared__ __attribute__((aligned(16))) float Xs[2][MC * LDX];
@@ -263,8 +375,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     const int mbeg = blockIdx.z * rows_per_slice;
     const int mend = min(g.M, mbeg + rows_per_slice);
 
-    // X gather: thread owns k index k0 + 4*(t%16) for rows t/16 and t/16 + 16
-    const int xq = t & 15, xrow = t >> 4;
+    // X gather: this thread owns k index k0 + 4*xq for rows xrow + p*RPPX (fixed over the block's life)
+    const int xq = t % TPRX, xrow = t / TPRX;
     const int kidx = k0 + 4 * xq;
     const bool kok = kidx < g.K;
     const int tap = kidx >> g.cshift, ci = kidx & (g.Cin - 1);
@@ -272,11 +384,11 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     const int yq = t % TPRY, yrow = t / TPRY;
     const bool cok = (co0 + 4 * yq) < g.Cout;   // Cout % 4 may be != 0: guarded per element below
 
-    f32x4 rx[2], ry[YPASS];
+    f32x4 rx[XPASS], ry[YPASS];
     auto load_chunk = [&](int mc) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            int m = mc + xrow + p * 16;
+        for (int p = 0; p < XPASS; ++p) {
+            int m = mc + xrow + p * RPPX;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (kok && m < mend) {
                 int b = m / g.OHW, r = m - b * g.OHW;
@@ -307,7 +419,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(&Xs[buf][(xrow + p * 16) * LDX + 4 * xq]) = rx[p];
+        for (int p = 0; p < XPASS; ++p) *reinterpret_cast<f32x4*>(&Xs[buf][(xrow + p * RPPX) * LDX + 4 * xq]) = rx[p];
 #pragma unroll
         for (int p = 0; p < YPASS; ++p) {
             int rl = yrow + p * RPPY;
@@ -355,10 +467,19 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     }
 }
 
+// 128-wide K tiles double the MFMA work per barrier but halve the number of tiles: use them only
+// when the grid still covers the chip with the row slices available (M / 256)
+static inline int wgrad_bki(int M, int N, int K) {
+    if (K < 512) return 64;
+    const int bco = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+    const long blocks = (long)cdiv(K, 128) * cdiv(N, bco) * std::max(1, M / 256);
+    return blocks >= 1024 ? 128 : 64;
+}
+
 int wgrad_slices(const ConvGeom& g) {
     const int M = g.M(), K = g.K(), N = g.Cout;
     const int bco = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
-    const int tiles = cdiv(K, 64) * cdiv(N, bco);
+    const int tiles = cdiv(K, wgrad_bki(M, N, K)) * cdiv(N, bco);
     int S = cdiv(2048, tiles);
     const int maxS = std::max(1, M / 256);
     if (S > maxS) S = maxS;
@@ -374,20 +495,27 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     rps = cdiv(rps, 32) * 32;
     const int N = g.Cout;
     const int bco = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
-    dim3 grid(cdiv(g.K, 64), cdiv(N, bco), S);
-#define CMOOP_WG(BCO_)                                                                                          \
+    const int bki = wgrad_bki(g.M, g.Cout, g.K);
+    dim3 grid(cdiv(g.K, bki), cdiv(N, bco), S);
+#define CMOOP_WG2(BCO_, BKI_)                                                                                   \
     do {                                                                                                       \
         if (tm && tm->start)                                                                                   \
-            hipExtLaunchKernelGGL((igemm_wgrad_kernel<BCO_>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps); \
+            hipExtLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps); \
         else                                                                                                   \
-            hipLaunchKernelGGL((igemm_wgrad_kernel<BCO_>), grid, dim3(256), 0, s, X, dY, P, g, rps);             \
+            hipLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, X, dY, P, g, rps);       \
+    } while (0)
+#define CMOOP_WG(BCO_)                    \
+    do {                                  \
+        if (bki == 128) CMOOP_WG2(BCO_, 128); \
+        else CMOOP_WG2(BCO_, 64);         \
     } while (0)
     if (bco == 16) CMOOP_WG(16);
     else if (bco == 32) CMOOP_WG(32);
     else CMOOP_WG(64);
 #undef CMOOP_WG
+#undef CMOOP_WG2
     CMOOP_HIP(hipGetLastError());
-    return bco;
+    return bco * 1000 + bki;
 }
 
 // out[i] = sum_s P[s][i]: 64 elements x 4 slice lanes per block, fixed summation order

@@ -39,8 +39,11 @@ struct GemmTiming {
     hipEvent_t start = nullptr, stop = nullptr;
 };
 // returns the instantiation code BM*100000 + BN*100 + BK of the kernel that was launched
+// splitk_ws (optional, >= igemm_splitk_workspace(g) floats): lets under-filled grids split the K axis
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& g,
-                     const GemmEpilogue& e, hipStream_t s, const GemmTiming* tm = nullptr);
+                     const GemmEpilogue& e, hipStream_t s, const GemmTiming* tm = nullptr,
+                     float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
+size_t igemm_splitk_workspace(const ConvGeom& g);
 
 // dWt[n][k] = sum_m dY[m][n] * im2col(X)[m][k], split over S row-slices into P[S][N][K].
 int wgrad_slices(const ConvGeom& g);

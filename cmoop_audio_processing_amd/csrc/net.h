@@ -47,7 +47,8 @@ struct GemmHook {   // brackets every MFMA GEMM launch (HIP-event sampling)
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
                            float* red_ws, hipStream_t s, GemmHook* hook);
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
-                        float mask_scale, int accumulate, hipStream_t s, GemmHook* hook);
+                        float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws = nullptr,
+                        size_t sk_floats = 0);
 
 struct Act {
     float* data = nullptr;
@@ -120,8 +121,8 @@ class Net : public GemmHook {
     std::vector<void*> allocs_;
     int64_t n_params_ = 0;
     float *params_ = nullptr, *grads_ = nullptr, *adam_m_ = nullptr, *adam_v_ = nullptr, *snap_ = nullptr;
-    float *wgrad_ws_ = nullptr, *wd_ws_ = nullptr, *red_ws_ = nullptr;
-    size_t wgrad_ws_floats_ = 0, wd_ws_floats_ = 0, red_ws_floats_ = 0;
+    float *wgrad_ws_ = nullptr, *wd_ws_ = nullptr, *red_ws_ = nullptr, *splitk_ws_ = nullptr;
+    size_t wgrad_ws_floats_ = 0, wd_ws_floats_ = 0, red_ws_floats_ = 0, splitk_ws_floats_ = 0;
     double* acc_train_ = nullptr;   // [2]: loss sum, correct (int64 bits)
     double* acc_eval_ = nullptr;
     int logits_ = -1;

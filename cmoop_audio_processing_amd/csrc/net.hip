@@ -257,6 +257,14 @@ void Net::build_plan() {
             const ConvGeom g = geom_of(op, cfg_.batch);
             wgrad_ws_floats_ = std::max(wgrad_ws_floats_, (size_t)wgrad_slices(g) * g.Cout * g.K());
             wd_ws_floats_ = std::max(wd_ws_floats_, (size_t)g.Cout * g.K());
+            // split-K slabs: forward (train and inference batch) and dgrad (input-shaped output)
+            splitk_ws_floats_ = std::max(splitk_ws_floats_, igemm_splitk_workspace(g));
+            splitk_ws_floats_ = std::max(splitk_ws_floats_, igemm_splitk_workspace(geom_of(op, Bmax_)));
+            if (op.stride == 1 && ilog2_exact(op.Cout) >= 4) {
+                ConvGeom gd = g;
+                gd.H = g.OH; gd.W = g.OW; gd.Cin = g.Cout; gd.Cout = g.Cin; gd.OH = g.H; gd.OW = g.W;
+                splitk_ws_floats_ = std::max(splitk_ws_floats_, igemm_splitk_workspace(gd));
+            }
             const int64_t M = g.M();
             if (op.Cout % 4 == 0)
                 red_ws_floats_ = std::max(red_ws_floats_, (size_t)colreduce_blocks(M, op.Cout) * 2 * op.Cout + 2 * op.Cout);
@@ -273,6 +281,7 @@ void Net::build_plan() {
     }
     wgrad_ws_ = dalloc(wgrad_ws_floats_);
     wd_ws_ = dalloc(wd_ws_floats_);
+    splitk_ws_ = splitk_ws_floats_ ? dalloc(splitk_ws_floats_) : nullptr;
     red_ws_ = dalloc(red_ws_floats_ + 64);
     acc_train_ = reinterpret_cast<double*>(dalloc(8));
     acc_eval_ = acc_train_ + 2;
@@ -351,7 +360,7 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
 // `g` is the FORWARD geometry.  mask != null applies the ReLU (and dropout scale) backward of the
 // layer's input in the epilogue; accumulate adds into dX (second consumer of a tensor).
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
-                        float mask_scale, int accumulate, hipStream_t s, GemmHook* hook) {
+                        float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws, size_t sk_floats) {
     const int N = g.Cout;
     if (ilog2_exact(N) < 4) {   // output layer: K_dgrad = classes (10/11/35) -- tiny VALU kernel
         CMOOP_REQUIRE(g.KH == 1 && g.H == 1 && g.W == 1 && !accumulate, "non power-of-two C_out only supported for dense layers");
@@ -374,13 +383,13 @@ void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGe
     e.mask = mask;
     e.mask_scale = mask_scale;
     const GemmTiming* tm = hook ? hook->begin(0, 2.0 * gd.M() * (double)gd.Cout * gd.K()) : nullptr;
-    const int code = launch_igemm_fwd(dY, wd_ws, dX, gd, e, s, tm);
+    const int code = launch_igemm_fwd(dY, wd_ws, dX, gd, e, s, tm, sk_ws, sk_floats);
     if (hook) hook->end(code);
 }
 
 void Net::run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e) {
     const GemmTiming* tm = begin(cls, 2.0 * g.M() * (double)g.Cout * g.K());
-    end(launch_igemm_fwd(X, Wt, Y, g, e, stream_, tm));
+    end(launch_igemm_fwd(X, Wt, Y, g, e, stream_, tm, splitk_ws_, splitk_ws_floats_));
 }
 
 void Net::drain_profile() {
@@ -396,7 +405,7 @@ void Net::drain_profile() {
             const std::string name = ev_pool_[i].cls == 0
                 ? "igemm_fwd_kernel<" + std::to_string(bm) + ", " + std::to_string(bn) + ", " + std::to_string(bk) + ", " +
                       std::to_string(wm) + ">"
-                : "igemm_wgrad_kernel<" + std::to_string(code) + ">";
+                : "igemm_wgrad_kernel<" + std::to_string(code / 1000) + ", " + std::to_string(code % 1000) + ">";
             ProfileEntry& e = t.by_kernel[name];
             e.ms += ms;
             e.flops += ev_pool_[i].flops;
@@ -477,7 +486,7 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B) {
             conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, red_ws_, stream_, this);
             if (op.need_dgrad)
                 conv_backward_data(dY, params_ + op.w_off, ia.grad, g, wd_ws_, op.in_is_relu ? ia.data : nullptr,
-                                   op.in_mask_scale, op.dgrad_accumulate, stream_, this);
+                                   op.in_mask_scale, op.dgrad_accumulate, stream_, this, splitk_ws_, splitk_ws_floats_);
             break;
         }
         case OP_BN: {

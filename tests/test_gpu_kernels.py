@@ -41,7 +41,9 @@ CONV_CASES = [
     (3, 26, 10, 32, 64, 5, 1, 1),
     (2, 51, 20, 16, 32, 1, 2, 0),      # skip projection: 1x1 stride 2 SAME, odd height
     (2, 7, 5, 64, 128, 3, 1, 0),
-    (1, 13, 5, 256, 512, 5, 1, 1),     # K = 6400, two N tiles
+    (1, 13, 5, 256, 512, 5, 1, 1),     # K = 6400: under-filled grid -> split-K slabs + combine epilogue
+    (64, 13, 5, 128, 128, 3, 1, 1),    # deep-layer shape of the real nets (M = 4160): split-K
+    (16, 26, 10, 64, 128, 3, 1, 0),
     (64, 1, 1, 256, 64, 1, 1, 1),      # dense as 1x1 conv
     (5, 1, 1, 64, 10, 1, 1, 0),        # output layer: N = classes
     (3, 1, 1, 64, 35, 1, 1, 0),
@@ -76,6 +78,8 @@ BWD_CASES = [
     (64, 1, 1, 128, 64, 1, 1, 1),
     (7, 1, 1, 64, 10, 1, 1, 1),        # output layer dgrad (small VALU kernel), N % 4 != 0 bias path
     (64, 13, 5, 16, 32, 3, 1, 0),      # long reduction -> several wgrad slices
+    (64, 13, 5, 128, 128, 3, 1, 1),    # split-K dgrad with the ReLU mask in the combine kernel; 128-wide wgrad K tile
+    (8, 26, 10, 64, 64, 5, 1, 0),
 ]
 
 
