@@ -14,7 +14,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libcmoop_hip.so")
+LIB_PATH = os.environ.get("CMOOP_LIB_PATH") or os.path.join(CSRC, "libcmoop_hip.so")   # override: A/B kernel builds
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "cmoop.h")
 
 _lock = threading.Lock()

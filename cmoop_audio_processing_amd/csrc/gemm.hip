@@ -8,6 +8,7 @@
 // so the order of summation inside a 16-k group is a fixed permutation).
 #include "kernels.h"
 #include <hip/hip_ext.h>
+#include <mutex>
 
 namespace cmoop {
 
@@ -16,6 +17,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct GeomDev {
     int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad_t, pad_l;
     int M, K, cshift, OHW;
+    uint32_t ohw_magic, ohw_shift, ow_magic, ow_shift;   // exact n / OHW and n / OW for n < 2^31 (fastdiv)
+    int rcp_kw;            // ceil(65536 / KW): tap / KW == (tap * rcp_kw) >> 16 for tap < 64
+    const float* zeros;    // 16 zero floats: predicated-off lanes load from here (branch-free gathers)
 };
 struct EpiDev {
     const float* bias;
@@ -26,11 +30,48 @@ struct EpiDev {
     float drop_scale;
 };
 
+// Granlund-Montgomery division by an invariant: q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
+static void fastdiv_init(int d, uint32_t* magic, uint32_t* shift) {
+    uint32_t s = 0;
+    while ((1u << s) < (uint32_t)d) ++s;
+    *shift = s;
+    *magic = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << s) - (uint64_t)d)) / (uint64_t)d + 1);
+}
+__device__ __forceinline__ int fastdiv(int n, uint32_t magic, uint32_t shift) {
+    return (int)((__umulhi((uint32_t)n, magic) + (uint32_t)n) >> shift);
+}
+
+// one 64-byte page of zeros per device: the source of every predicated-off float4 gather
+static const float* zero_page() {
+    static thread_local const float* page[16] = {nullptr};
+    int dev = 0;
+    CMOOP_HIP(hipGetDevice(&dev));
+    CMOOP_REQUIRE(dev >= 0 && dev < 16, "device index out of range");
+    if (!page[dev]) {
+        static std::mutex mu;
+        static const float* shared[16] = {nullptr};
+        std::lock_guard<std::mutex> l(mu);
+        if (!shared[dev]) {
+            float* p = nullptr;
+            CMOOP_HIP(hipMalloc(&p, 256));
+            CMOOP_HIP(hipMemset(p, 0, 256));
+            shared[dev] = p;
+        }
+        page[dev] = shared[dev];
+    }
+    return page[dev];
+}
+
 static GeomDev to_dev(const ConvGeom& g) {
     GeomDev d;
     d.B = g.B; d.H = g.H; d.W = g.W; d.Cin = g.Cin; d.OH = g.OH; d.OW = g.OW; d.Cout = g.Cout;
     d.KH = g.KH; d.KW = g.KW; d.stride = g.stride; d.pad_t = g.pad_t; d.pad_l = g.pad_l;
     d.M = g.M(); d.K = g.K(); d.cshift = ilog2_exact(g.Cin); d.OHW = g.OH * g.OW;
+    d.rcp_kw = (65536 + g.KW - 1) / g.KW;
+    fastdiv_init(d.OHW, &d.ohw_magic, &d.ohw_shift);
+    fastdiv_init(g.OW, &d.ow_magic, &d.ow_shift);
+    d.zeros = zero_page();
+    CMOOP_REQUIRE(g.KH * g.KW <= 64, "kernel window too large");
     CMOOP_REQUIRE(d.cshift >= 4, "implicit GEMM needs C_in a power of two >= 16");
     CMOOP_REQUIRE((int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31), "input tensor too large for 32-bit indexing");
     CMOOP_REQUIRE((int64_t)d.M * g.Cout < (1ll << 31), "output tensor too large for 32-bit indexing");
@@ -72,8 +113,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         int m = m0 + ml;
         a_ok[p] = ml < BM && m < g.M;
         int mm = a_ok[p] ? m : 0;
-        int b = mm / g.OHW, r = mm - b * g.OHW;
-        int oh = r / g.OW, ow = r - oh * g.OW;
+        int b = fastdiv(mm, g.ohw_magic, g.ohw_shift), r = mm - b * g.OHW;
+        int oh = fastdiv(r, g.ow_magic, g.ow_shift), ow = r - oh * g.OW;
         a_ih0[p] = oh * g.stride - g.pad_t;
         a_iw0[p] = ow * g.stride - g.pad_l;
         a_base[p] = b * g.H * g.W;
@@ -87,22 +128,20 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         const int kidx = c * BK + 4 * kq;
         const bool kok = kidx < g.K;
         const int tap = kidx >> g.cshift, ci = kidx & (g.Cin - 1);
-        const int kh = tap / g.KW, kw = tap - kh * g.KW;
+        const int kh = (tap * g.rcp_kw) >> 16, kw = tap - kh * g.KW;
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
             int ih = a_ih0[p] + kh, iw = a_iw0[p] + kw;
             bool ok = kok && a_ok[p] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(X + (((size_t)(a_base[p] + ih * g.W + iw)) << g.cshift) + ci);
-            ra[p] = v;
+            const float* src = ok ? X + (((size_t)(a_base[p] + ih * g.W + iw)) << g.cshift) + ci : g.zeros;
+            ra[p] = *reinterpret_cast<const f32x4*>(src);
         }
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             int nl = lrow + p * RPP;
             int n = n0 + nl;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (nl < BN && n < g.Cout && kok) v = *reinterpret_cast<const f32x4*>(Wt + (size_t)n * g.K + kidx);
-            rb[p] = v;
+            const float* src = (nl < BN && n < g.Cout && kok) ? Wt + (size_t)n * g.K + kidx : g.zeros;
+            rb[p] = *reinterpret_cast<const f32x4*>(src);
         }
     };
     auto store_chunk = [&](int buf, const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
@@ -380,7 +419,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     const int kidx = k0 + 4 * xq;
     const bool kok = kidx < g.K;
     const int tap = kidx >> g.cshift, ci = kidx & (g.Cin - 1);
-    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    const int kh = (tap * g.rcp_kw) >> 16, kw = tap - kh * g.KW;
     const int yq = t % TPRY, yrow = t / TPRY;
     const bool cok = (co0 + 4 * yq) < g.Cout;   // Cout % 4 may be != 0: guarded per element below
 
@@ -388,31 +427,29 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     auto load_chunk = [&](int mc) {
 #pragma unroll
         for (int p = 0; p < XPASS; ++p) {
-            int m = mc + xrow + p * RPPX;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kok && m < mend) {
-                int b = m / g.OHW, r = m - b * g.OHW;
-                int oh = r / g.OW, ow = r - oh * g.OW;
-                int ih = oh * g.stride - g.pad_t + kh, iw = ow * g.stride - g.pad_l + kw;
-                if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-                    v = *reinterpret_cast<const f32x4*>(X + (((size_t)((b * g.H + ih) * g.W + iw)) << g.cshift) + ci);
-            }
-            rx[p] = v;
+            const int m = mc + xrow + p * RPPX;
+            const int mm = m < mend ? m : 0;
+            const int b = fastdiv(mm, g.ohw_magic, g.ohw_shift), r = mm - b * g.OHW;
+            const int oh = fastdiv(r, g.ow_magic, g.ow_shift), ow = r - oh * g.OW;
+            const int ih = oh * g.stride - g.pad_t + kh, iw = ow * g.stride - g.pad_l + kw;
+            const bool ok = kok && m < mend && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+            const float* src = ok ? X + (((size_t)((b * g.H + ih) * g.W + iw)) << g.cshift) + ci : g.zeros;
+            rx[p] = *reinterpret_cast<const f32x4*>(src);
         }
 #pragma unroll
         for (int p = 0; p < YPASS; ++p) {
             int rl = yrow + p * RPPY;
             int m = mc + rl;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (rl < MC && m < mend && cok) {
+            const bool ok = rl < MC && m < mend && cok;
+            if ((g.Cout & 3) == 0) {      // wave-uniform: every conv / hidden dense layer
+                const float* src = ok ? dY + (size_t)m * g.Cout + co0 + 4 * yq : g.zeros;
+                v = *reinterpret_cast<const f32x4*>(src);
+            } else if (ok) {              // output layer (10 / 11 / 35 classes)
                 const float* src = dY + (size_t)m * g.Cout + co0 + 4 * yq;
-                if (co0 + 4 * yq + 3 < g.Cout && (g.Cout & 3) == 0) {
-                    v = *reinterpret_cast<const f32x4*>(src);
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (co0 + 4 * yq + j < g.Cout) v[j] = src[j];
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (co0 + 4 * yq + j < g.Cout) v[j] = src[j];
             }
             ry[p] = v;
         }
