@@ -120,6 +120,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # under rocprofv3 the tool library crashes on hipExtLaunchKernelGGL (ROCm 7.2): fall back to plain
+    # hipEventRecord pairs around the sampled launches there (slightly inflated when streams overlap)
+    under_rocprof = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if under_rocprof:
+        os.environ["CMOOP_PROFILE_PAIRS"] = "1"
+
     import torch
     import torch.distributed as dist
     from cmoop_audio_processing_amd import EvalConfig, PopulationEvaluator, _lib, frontend, genes as G
@@ -206,6 +212,7 @@ def main():
         roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                     "kernel": dom["kernel"], "sampled_launches": dom["launches"],
+                    "timing": "hipEventRecord pairs (under rocprofv3)" if under_rocprof else "hipExtLaunchKernelGGL start/stop events",
                     "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5),
                     "all_mfma_kernels_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 3) if tot_ms > 0 else None,
                     "per_kernel": [{"kernel": e["kernel"], "launches": e["launches"],

@@ -285,7 +285,7 @@ int cmoop_conv_bwd(const float* x, const float* w, const float* dy, float* dx, f
         }
         const ConvGeom g = make_geom(B, H, W, Cin, Cout, KS, stride);
         float *wg = nullptr, *red = nullptr, *wd = nullptr, *sk = nullptr;
-        CMOOP_HIP(hipMalloc(&wg, (size_t)wgrad_slices(g) * g.Cout * g.K() * 4));
+        CMOOP_HIP(hipMalloc(&wg, (size_t)wgrad_slices(g) * g.Cout * (g.K() + 1) * 4));
         CMOOP_HIP(hipMalloc(&red, ((size_t)1024 * 2 * Cout + 2 * Cout + 64) * 4));
         CMOOP_HIP(hipMalloc(&wd, (size_t)g.Cout * g.K() * 4));
         conv_backward_weights(x, dy, dw, db, g, wg, red, s, nullptr);

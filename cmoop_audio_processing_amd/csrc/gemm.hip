@@ -273,30 +273,46 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     }
 }
 
-// combine the split-K slabs in fixed order and apply the epilogue
+// combine the split-K slabs in fixed order and apply the epilogue (VEC = 4 when N % 4 == 0)
+template <int VEC>
 __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ P, float* __restrict__ Y, GeomDev g,
                                                              EpiDev e, int splits) {
     const int N = g.Cout;
     const size_t total = (size_t)g.M * N;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += (size_t)gridDim.x * 256 * VEC) {
         const int row = (int)(i / N), col = (int)(i - (size_t)row * N);
-        float v = 0.f;
-        for (int z = 0; z < splits; ++z) v += P[(size_t)z * total + i];
-        if (e.bias) v += e.bias[col];
-        if (e.relu) v = fmaxf(v, 0.f);
+        float v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = 0.f;
+        for (int z = 0; z < splits; ++z) {
+            if constexpr (VEC == 4) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(P + (size_t)z * total + i);
+                v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+            } else {
+                v[0] += P[(size_t)z * total + i];
+            }
+        }
         size_t off = i;
         if (e.out_stride != 1) {
-            int b = row / g.OHW, rr = row - b * g.OHW;
-            int oh = rr / g.OW, ow = rr - oh * g.OW;
+            int b = fastdiv(row, g.ohw_magic, g.ohw_shift), rr = row - b * g.OHW;
+            int oh = fastdiv(rr, g.ow_magic, g.ow_shift), ow = rr - oh * g.OW;
             off = ((size_t)(b * e.OHf + oh * e.out_stride) * e.OWf + ow * e.out_stride) * N + col;
         }
-        if (e.dropout) {
-            uint32_t u24 = fmix32(e.drop_prefix ^ (uint32_t)i) >> 8;
-            v = (u24 >= e.drop_thr) ? v * e.drop_scale : 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float x = v[j];
+            if (e.bias) x += e.bias[col + j];
+            if (e.relu) x = fmaxf(x, 0.f);
+            if (e.dropout) {
+                uint32_t u24 = fmix32(e.drop_prefix ^ (uint32_t)(i + j)) >> 8;
+                x = (u24 >= e.drop_thr) ? x * e.drop_scale : 0.f;
+            }
+            if (e.mask) x = (e.mask[off + j] > 0.f) ? x * e.mask_scale : 0.f;
+            if (e.accumulate) x += Y[off + j];
+            v[j] = x;
         }
-        if (e.mask) v = (e.mask[off] > 0.f) ? v * e.mask_scale : 0.f;
-        if (e.accumulate) v += Y[off];
-        Y[off] = v;
+        if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(Y + off) = f32x4{v[0], v[1], v[2], v[3]};
+        else Y[off] = v[0];
     }
 }
 
@@ -307,16 +323,24 @@ static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDe
     const int nchunks = cdiv(g.K, BK);
     const int cps = cdiv(nchunks, splits);
     float* sl = splits > 1 ? slab : nullptr;
-    if (tm && tm->start)
+    if (tm && tm->start && tm->ext) {
         hipExtLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, Wt, Y, g, e,
                               sl, cps);
-    else
+    } else {
+        if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));
         hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM>), grid, dim3(256), 0, s, X, Wt, Y, g, e, sl, cps);
+        if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));
+    }
     CMOOP_HIP(hipGetLastError());
     if (splits > 1) {
         const size_t total = (size_t)g.M * g.Cout;
-        const unsigned gridc = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(splitk_combine_kernel, dim3(gridc), dim3(256), 0, s, slab, Y, g, e, splits);
+        if (g.Cout % 4 == 0) {
+            const unsigned gridc = (unsigned)std::min<size_t>((total / 4 + 255) / 256, 4096);
+            hipLaunchKernelGGL(splitk_combine_kernel<4>, dim3(gridc), dim3(256), 0, s, slab, Y, g, e, splits);
+        } else {
+            const unsigned gridc = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+            hipLaunchKernelGGL(splitk_combine_kernel<1>, dim3(gridc), dim3(256), 0, s, slab, Y, g, e, splits);
+        }
         CMOOP_HIP(hipGetLastError());
     }
 }
@@ -331,8 +355,10 @@ static void pick_tile(int M, int N, int K, int bk, size_t ws_floats, int* bm, in
     long blocks = (long)cdiv(M, 128) * cdiv(N, bn_big);
     if (blocks >= 384) { *bm = 128; *bn = bn_big; return; }
     const int nchunks = cdiv(K, bk);
-    if (nchunks >= 16 && ws_floats > 0) {
-        int sp = (int)std::min<long>(cdiv(768, (int)blocks), nchunks / 8);
+    if (nchunks >= (M <= 512 ? 4 : 16) && ws_floats > 0) {
+        // dense layers (M = batch rows) are a serial latency chain of K chunks: split them finely
+        const int min_chunks = M <= 512 ? 2 : 8;
+        int sp = (int)std::min<long>(cdiv(768, (int)blocks), nchunks / min_chunks);
         sp = std::min(sp, 32);
         while (sp > 1 && (size_t)sp * M * N > ws_floats) --sp;
         if (sp > 1) {
@@ -397,7 +423,8 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
 // ---------------------------------------------------------------------------
 template <int BCO, int BKI>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
-                                                          float* __restrict__ P, GeomDev g, int rows_per_slice) {
+                                                          float* __restrict__ P, GeomDev g, int rows_per_slice,
+                                                          float* __restrict__ Pbias) {
     constexpr int MC = 32;
     constexpr int LDX = BKI + 16;                          // == 16 mod 32
     constexpr int LDY = (BCO == 16) ? 16 : BCO + 16;
@@ -470,6 +497,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < KPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // bias gradient (column sums of dY) rides along in the blocks of the first K tile
+    const bool do_bias = Pbias != nullptr && blockIdx.x == 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const int nchunks = (mend > mbeg) ? (mend - mbeg + MC - 1) / MC : 0;
     if (nchunks > 0) {
         load_chunk(mbeg);
@@ -478,6 +508,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
+        if (do_bias) {
+#pragma unroll
+            for (int p = 0; p < YPASS; ++p) bsum += ry[p];   // ry still holds chunk c (rows past mend are zero)
+        }
         if (c + 1 < nchunks) load_chunk(mbeg + (c + 1) * MC);
 #pragma unroll
         for (int st = 0; st < MC / 4; ++st) {
@@ -492,6 +526,17 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
         __syncthreads();
     }
 
+    if (do_bias) {   // fixed-order reduction over the RPPY row lanes that share a column group
+        float* red = &Xs[0][0];                       // MC*LDX*2 >= 1024 floats, free after the loop's last barrier
+        *reinterpret_cast<f32x4*>(&red[4 * t]) = bsum;
+        __syncthreads();
+        if (t < BCO && co0 + t < g.Cout) {
+            const int q4 = t >> 2, j = t & 3;
+            float sacc = 0.f;
+            for (int r = 0; r < RPPY; ++r) sacc += red[4 * (r * TPRY + q4) + j];
+            Pbias[(size_t)blockIdx.z * g.Cout + co0 + t] = sacc;
+        }
+    }
     float* Pout = P + (size_t)blockIdx.z * g.Cout * g.K;
 #pragma unroll
     for (int kt = 0; kt < KPW; ++kt) {
@@ -518,6 +563,10 @@ int wgrad_slices(const ConvGeom& g) {
     const int bco = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
     const int tiles = cdiv(K, wgrad_bki(M, N, K)) * cdiv(N, bco);
     int S = cdiv(2048, tiles);
+    // cap the slab traffic (S*N*K floats written and read back): at most ~4M floats, but keep >= 8 slices
+    const int64_t nk = (int64_t)N * K;
+    const int cap = (int)std::max<int64_t>(8, (4ll << 20) / std::max<int64_t>(nk, 1));
+    if (S > cap) S = cap;
     const int maxS = std::max(1, M / 256);
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
@@ -525,7 +574,7 @@ int wgrad_slices(const ConvGeom& g) {
 }
 
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s,
-                       const GemmTiming* tm) {
+                       const GemmTiming* tm, float* Pbias) {
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
     int rps = cdiv(g.M, S);
@@ -536,10 +585,13 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     dim3 grid(cdiv(g.K, bki), cdiv(N, bco), S);
 #define CMOOP_WG2(BCO_, BKI_)                                                                                   \
     do {                                                                                                       \
-        if (tm && tm->start)                                                                                   \
-            hipExtLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps); \
-        else                                                                                                   \
-            hipLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, X, dY, P, g, rps);       \
+        if (tm && tm->start && tm->ext) {                                                                      \
+            hipExtLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps, Pbias); \
+        } else {                                                                                               \
+            if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));                                      \
+            hipLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, X, dY, P, g, rps, Pbias); \
+            if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));                                       \
+        }                                                                                                      \
     } while (0)
 #define CMOOP_WG(BCO_)                    \
     do {                                  \

@@ -34,9 +34,12 @@ struct GemmEpilogue {
 };
 
 // Y[m][n] = sum_k im2col(X)[m][k] * Wt[n][k]  (+ epilogue).  Cin must be a power of two >= 16.
-// optional start/stop events filled with the kernel's own begin/end (hipExtLaunchKernelGGL)
+// optional start/stop events.  ext: filled with the kernel's own begin/end by hipExtLaunchKernelGGL
+// (exact even with other streams in flight); !ext: plain hipEventRecord pair around the launch
+// (what works under rocprofv3, whose tool library crashes on ext launches in ROCm 7.2).
 struct GemmTiming {
     hipEvent_t start = nullptr, stop = nullptr;
+    bool ext = true;
 };
 // returns the instantiation code BM*100000 + BN*100 + BK of the kernel that was launched
 // splitk_ws (optional, >= igemm_splitk_workspace(g) floats): lets under-filled grids split the K axis
@@ -48,8 +51,9 @@ size_t igemm_splitk_workspace(const ConvGeom& g);
 // dWt[n][k] = sum_m dY[m][n] * im2col(X)[m][k], split over S row-slices into P[S][N][K].
 int wgrad_slices(const ConvGeom& g);
 // returns the instantiation code BCO of the kernel that was launched
+// Pbias (optional): [S][N] per-slice column sums of dY (the bias gradient), fused into the first K tile's blocks
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& g, int S, hipStream_t s,
-                       const GemmTiming* tm = nullptr);
+                       const GemmTiming* tm = nullptr, float* Pbias = nullptr);
 // out[i] = sum_s P[s][i]  (fixed order -> deterministic)
 void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s);
 // Wd[ci][KH-1-kh][KW-1-kw][co] = W[co][kh][kw][ci]   (operand of the dgrad implicit GEMM)

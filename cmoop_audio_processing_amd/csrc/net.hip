@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -255,7 +256,7 @@ void Net::build_plan() {
         }
         if (op.kind == OP_CONV || op.kind == OP_DENSE) {
             const ConvGeom g = geom_of(op, cfg_.batch);
-            wgrad_ws_floats_ = std::max(wgrad_ws_floats_, (size_t)wgrad_slices(g) * g.Cout * g.K());
+            wgrad_ws_floats_ = std::max(wgrad_ws_floats_, (size_t)wgrad_slices(g) * g.Cout * (g.K() + 1));
             wd_ws_floats_ = std::max(wd_ws_floats_, (size_t)g.Cout * g.K());
             // split-K slabs: forward (train and inference batch) and dgrad (input-shaped output)
             splitk_ws_floats_ = std::max(splitk_ws_floats_, igemm_splitk_workspace(g));
@@ -288,7 +289,16 @@ void Net::build_plan() {
     CMOOP_HIP(hipMemsetAsync(acc_train_, 0, 32, stream_));
     if (cfg_.profile_every > 0) {
         ev_pool_.resize(1024);
-        for (auto& e : ev_pool_) { CMOOP_HIP(hipEventCreate(&e.t.start)); CMOOP_HIP(hipEventCreate(&e.t.stop)); }
+        // CMOOP_PROFILE_PAIRS=1 (set by bench.py when it runs under rocprofv3): plain event pairs
+        const char* pm = std::getenv("CMOOP_PROFILE_PAIRS");
+        const bool ext = !(pm && pm[0] == '1');
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true)) std::fprintf(stderr, "[cmoop] GEMM launch timing: %s\n", ext ? "hipExtLaunchKernelGGL events" : "hipEventRecord pairs");
+        for (auto& e : ev_pool_) {
+            CMOOP_HIP(hipEventCreate(&e.t.start));
+            CMOOP_HIP(hipEventCreate(&e.t.stop));
+            e.t.ext = ext;
+        }
     }
 }
 
@@ -343,17 +353,17 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
                            float* red_ws, hipStream_t s, GemmHook* hook) {
     const int M = g.M(), N = g.Cout, K = g.K();
     const int S = wgrad_slices(g);
+    // one slice (dense layers, deep convs): the kernel writes the gradients in place
+    float* Pk = S == 1 ? dW : wgrad_ws;
+    float* Pbias = S == 1 ? dB : wgrad_ws + (size_t)S * N * K;      // [S][N] right after the kernel-gradient slabs
     const GemmTiming* tm = hook ? hook->begin(1, 2.0 * M * (double)N * K) : nullptr;
-    const int code = launch_igemm_wgrad(X, dY, wgrad_ws, g, S, s, tm);
+    const int code = launch_igemm_wgrad(X, dY, Pk, g, S, s, tm, Pbias);
     if (hook) hook->end(code);
-    launch_reduce_slices(wgrad_ws, dW, S, (int64_t)N * K, s);
-    if (N % 4 == 0) {
-        const int nb = colreduce_blocks(M, N);
-        launch_colstats(dY, red_ws, M, N, nb, s);
-        launch_colsum_finalize(red_ws, nb, N, dB, s);
-    } else {
-        launch_colsum_small(dY, dB, M, N, s);
+    if (S > 1) {
+        launch_reduce_slices(wgrad_ws, dW, S, (int64_t)N * K, s);
+        launch_reduce_slices(Pbias, dB, S, N, s);
     }
+    (void)red_ws;
 }
 
 // dX of a conv / dense layer: the same implicit-GEMM kernel on dY with flip-transposed weights.
