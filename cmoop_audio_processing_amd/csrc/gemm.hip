@@ -100,7 +100,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
 
     const int t = threadIdx.x;
-    const int m0 = blockIdx.x * BM;
+    // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each
+    // XCD a contiguous run of M tiles -- neighbouring tiles share their im2col halo in that XCD's L2.
+    int mtile = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = mtile & 7, idx = mtile >> 3;
+        const int qn = nwg >> 3, rn = nwg & 7;
+        mtile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+    }
+    const int m0 = mtile * BM;
     const int n0 = blockIdx.y * BN;
     const int lrow = t / TPR, kq = t % TPR;
 
@@ -429,7 +437,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     constexpr int LDX = BKI + 16;                          // == 16 mod 32
     constexpr int LDY = (BCO == 16) ? 16 : BCO + 16;
     constexpr int CT = BCO / 16, KT = BKI / 16;             // co tiles, k tiles of the block
-    constexpr int KPW = KT * CT / 4;                        // k tiles per wave
+    constexpr int WC = CT >= 8 ? 2 : (CT >= 4 ? 4 : CT);    // waves along co; 4 / WC along k
+    constexpr int WK = 4 / WC;
+    constexpr int CPW = CT / WC, KPW = KT / WK;             // co tiles / k tiles per wave
     constexpr int TPRX = BKI / 4, RPPX = 256 / TPRX, XPASS = MC / RPPX;
     constexpr int TPRY = BCO / 4, RPPY = 256 / TPRY;
     constexpr int YPASS = (MC + RPPY - 1) / RPPY;
@@ -492,10 +502,12 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     };
 
     const int wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
-    const int co_t = wave % CT, kgrp = wave / CT;
-    f32x4 acc[KPW];
+    const int wave_c = wave % WC, wave_k = wave / WC;
+    f32x4 acc[CPW][KPW];
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < CPW; ++i)
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // bias gradient (column sums of dY) rides along in the blocks of the first K tile
     const bool do_bias = Pbias != nullptr && blockIdx.x == 0;
@@ -515,12 +527,16 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
         if (c + 1 < nchunks) load_chunk(mbeg + (c + 1) * MC);
 #pragma unroll
         for (int st = 0; st < MC / 4; ++st) {
-            const float a = Ys[buf][(st * 4 + q) * LDY + co_t * 16 + lr];
+            float a[CPW], b[KPW];
 #pragma unroll
-            for (int kt = 0; kt < KPW; ++kt) {
-                const float b = Xs[buf][(st * 4 + q) * LDX + (kgrp * KPW + kt) * 16 + lr];
-                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[kt], 0, 0, 0);
-            }
+            for (int c2 = 0; c2 < CPW; ++c2) a[c2] = Ys[buf][(st * 4 + q) * LDY + (wave_c * CPW + c2) * 16 + lr];
+#pragma unroll
+            for (int kt = 0; kt < KPW; ++kt) b[kt] = Xs[buf][(st * 4 + q) * LDX + (wave_k * KPW + kt) * 16 + lr];
+#pragma unroll
+            for (int c2 = 0; c2 < CPW; ++c2)
+#pragma unroll
+                for (int kt = 0; kt < KPW; ++kt)
+                    acc[c2][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c2], b[kt], acc[c2][kt], 0, 0, 0);
         }
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
@@ -539,28 +555,31 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     }
     float* Pout = P + (size_t)blockIdx.z * g.Cout * g.K;
 #pragma unroll
-    for (int kt = 0; kt < KPW; ++kt) {
-        const int kcol = k0 + (kgrp * KPW + kt) * 16 + lr;
+    for (int c2 = 0; c2 < CPW; ++c2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + co_t * 16 + q * 4 + r;
-            if (co < g.Cout && kcol < g.K) Pout[(size_t)co * g.K + kcol] = acc[kt][r];
+        for (int kt = 0; kt < KPW; ++kt) {
+            const int kcol = k0 + (wave_k * KPW + kt) * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (wave_c * CPW + c2) * 16 + q * 4 + r;
+                if (co < g.Cout && kcol < g.K) Pout[(size_t)co * g.K + kcol] = acc[c2][kt][r];
+            }
         }
-    }
 }
 
 // 128-wide K tiles double the MFMA work per barrier but halve the number of tiles: use them only
 // when the grid still covers the chip with the row slices available (M / 256)
+static inline int wgrad_bco(int N) { return N <= 16 ? 16 : (N <= 32 ? 32 : (N <= 64 ? 64 : 128)); }
 static inline int wgrad_bki(int M, int N, int K) {
     if (K < 512) return 64;
-    const int bco = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+    const int bco = wgrad_bco(N);
     const long blocks = (long)cdiv(K, 128) * cdiv(N, bco) * std::max(1, M / 256);
     return blocks >= 1024 ? 128 : 64;
 }
 
 int wgrad_slices(const ConvGeom& g) {
     const int M = g.M(), K = g.K(), N = g.Cout;
-    const int bco = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+    const int bco = wgrad_bco(N);
     const int tiles = cdiv(K, wgrad_bki(M, N, K)) * cdiv(N, bco);
     int S = cdiv(2048, tiles);
     // cap the slab traffic (S*N*K floats written and read back): at most ~4M floats, but keep >= 8 slices
@@ -580,7 +599,7 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     int rps = cdiv(g.M, S);
     rps = cdiv(rps, 32) * 32;
     const int N = g.Cout;
-    const int bco = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+    const int bco = wgrad_bco(N);
     const int bki = wgrad_bki(g.M, g.Cout, g.K);
     dim3 grid(cdiv(g.K, bki), cdiv(N, bco), S);
 #define CMOOP_WG2(BCO_, BKI_)                                                                                   \
@@ -600,7 +619,8 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     } while (0)
     if (bco == 16) CMOOP_WG(16);
     else if (bco == 32) CMOOP_WG(32);
-    else CMOOP_WG(64);
+    else if (bco == 64) CMOOP_WG(64);
+    else CMOOP_WG(128);
 #undef CMOOP_WG
 #undef CMOOP_WG2
     CMOOP_HIP(hipGetLastError());
