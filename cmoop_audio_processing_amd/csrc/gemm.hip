@@ -183,6 +183,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
                 b[ct] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wcol + ct * 16 + lr) * LDK + kk * 16 + q * 4]);
+            // raised priority over the MFMA burst: the co-resident wave's address VALU no longer wins
+            // issue arbitration against it (+3..6 % measured, same-box A/B)
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][j], b[ct][j], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     };
 
@@ -353,6 +357,22 @@ static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDe
     }
 }
 
+// Pick a multiplier m in [1, max_mult] for `base` workgroups so that base*m fills whole waves of
+// `resident` co-resident workgroups (256 CUs x workgroups per CU): the smallest m whose last wave is
+// >= 85 % full, else the best-filled one.  Few-wave grids otherwise pay up to 2x for a ragged tail.
+static int fill_waves(long base, int max_mult, int resident) {
+    int best = 1;
+    double best_u = 0.0;
+    for (int m = 1; m <= max_mult; ++m) {
+        const long blocks = base * m;
+        const long waves = (blocks + resident - 1) / resident;
+        const double u = (double)blocks / (double)(waves * resident);
+        if (blocks >= resident / 2 && u >= 0.85) return m;
+        if (u > best_u) { best_u = u; best = m; }
+    }
+    return best;
+}
+
 // Tile / split choice.  Prefer the big (most efficient) tile; if its grid does not cover the chip
 // (deep layers: 13x5 or 26x10 pixels x 64 samples) split the long K axis across blockIdx.z when a
 // slab workspace is available, else fall back to 64-row tiles.
@@ -366,8 +386,9 @@ static void pick_tile(int M, int N, int K, int bk, size_t ws_floats, int* bm, in
     if (nchunks >= (M <= 512 ? 4 : 16) && ws_floats > 0) {
         // dense layers (M = batch rows) are a serial latency chain of K chunks: split them finely
         const int min_chunks = M <= 512 ? 2 : 8;
-        int sp = (int)std::min<long>(cdiv(768, (int)blocks), nchunks / min_chunks);
+        int sp = (int)std::min<long>(cdiv(1024, (int)blocks), nchunks / min_chunks);
         sp = std::min(sp, 32);
+        if (sp > 1) sp = fill_waves(blocks, sp, 512);
         while (sp > 1 && (size_t)sp * M * N > ws_floats) --sp;
         if (sp > 1) {
             const int cps = cdiv(nchunks, sp);
@@ -387,7 +408,7 @@ size_t igemm_splitk_workspace(const ConvGeom& g) {
     const int bn_big = N > 64 ? 128 : (N <= 16 ? 16 : (N <= 32 ? 32 : 64));
     const long blocks = (long)cdiv(M, 128) * cdiv(N, bn_big);
     if (blocks >= 384) return 0;
-    const int sp = std::min(32, cdiv(768, (int)blocks));
+    const int sp = std::min(32, cdiv(1024, (int)blocks));
     return (size_t)sp * M * N;
 }
 
@@ -532,11 +553,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
             for (int c2 = 0; c2 < CPW; ++c2) a[c2] = Ys[buf][(st * 4 + q) * LDY + (wave_c * CPW + c2) * 16 + lr];
 #pragma unroll
             for (int kt = 0; kt < KPW; ++kt) b[kt] = Xs[buf][(st * 4 + q) * LDX + (wave_k * KPW + kt) * 16 + lr];
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int c2 = 0; c2 < CPW; ++c2)
 #pragma unroll
                 for (int kt = 0; kt < KPW; ++kt)
                     acc[c2][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c2], b[kt], acc[c2][kt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
@@ -582,10 +605,18 @@ int wgrad_slices(const ConvGeom& g) {
     const int bco = wgrad_bco(N);
     const int tiles = cdiv(K, wgrad_bki(M, N, K)) * cdiv(N, bco);
     int S = cdiv(2048, tiles);
-    // cap the slab traffic (S*N*K floats written and read back): at most ~4M floats, but keep >= 8 slices
+    // cap the slab traffic (S*N*K floats written and read back): at most ~16M floats, but keep >= 8 slices
     const int64_t nk = (int64_t)N * K;
-    const int cap = (int)std::max<int64_t>(8, (4ll << 20) / std::max<int64_t>(nk, 1));
+    const int cap = (int)std::max<int64_t>(8, (16ll << 20) / std::max<int64_t>(nk, 1));
     if (S > cap) S = cap;
+    const int maxS0 = std::max(1, M / 256);
+    if (S > maxS0) S = maxS0;
+    // few-wave grids: choose the slice count that fills whole waves of co-resident workgroups
+    // (LDS-limited occupancy of each instantiation: 160 KiB / LDS per workgroup)
+    const int bki = wgrad_bki(M, N, K);
+    const int lds_bytes = 2 * 32 * ((bki + 16) + (bco == 16 ? 16 : bco + 16)) * 4;
+    const int resident = 256 * std::max(1, std::min(8, (160 * 1024) / lds_bytes));
+    if ((long)tiles * S < 4l * resident) S = fill_waves(tiles, S, resident);
     const int maxS = std::max(1, M / 256);
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
