@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=2, help="fixed epoch budget per candidate; 10 = full SURVEY §8d protocol")
     ap.add_argument("--variant", default="A")
     ap.add_argument("--classes", type=int, default=10)
-    ap.add_argument("--slots", type=int, default=4)
+    ap.add_argument("--slots", type=int, default=8, help="candidates in flight per GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--weak", action="store_true", help="population = pop * gpus")
     ap.add_argument("--profile-every", type=int, default=25)
@@ -220,10 +220,37 @@ def main():
                                     "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else None}
                                    for e in sorted(entries, key=lambda e: -e["ms"])]}
 
+    # ---- the same MFMA kernels ALONE on the GPU (single stream, after the timed region): with several
+    # candidates in flight the per-launch durations above are stretched by the kernels they share the
+    # CUs with, so they understate kernel quality; this leg is the per-kernel roofline fraction.
+    if rank == 0 and roofline is not None:
+        iso = []
+        for (B, H, W, Cin, Cout, KS) in ((64, 101, 40, 64, 64, 5), (64, 51, 20, 128, 128, 5), (64, 26, 10, 256, 256, 5)):
+            x = torch.randn((B, H, W, Cin), device=dev)
+            w = torch.randn((Cout, KS, KS, Cin), device=dev) * 0.05
+            b = torch.randn((Cout,), device=dev)
+            yb = torch.randn((B, H, W, Cout), device=dev)
+            torch.cuda.synchronize()
+            fl = 2.0 * B * H * W * Cout * KS * KS * Cin
+            ent = {"conv": f"B{B} {H}x{W} {Cin}->{Cout} k{KS}", "gflop": round(fl / 1e9, 2)}
+            for mode, nm in ((0, "fwd"), (1, "dgrad"), (2, "wgrad")):
+                ms = C.c_double()
+                _lib.check(L.cmoop_conv_time(mode, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(yb), B, H, W, Cin, Cout, KS, 20,
+                                             C.byref(ms)))
+                ent[nm + "_tflops"] = round(fl / ms.value / 1e9, 1)
+            iso.append(ent)
+        roofline["isolated_single_stream"] = iso
+        roofline["isolated_frac_best"] = round(max(max(e["fwd_tflops"], e["dgrad_tflops"], e["wgrad_tflops"]) for e in iso)
+                                               / PEAK_FP32_MFMA_TFLOPS, 4)
+        roofline["concurrent_streams"] = args.slots
+
     if rank == 0:
         evals = n_pop * args.steps
         value = evals / (elapsed / 3600.0)
         work = sum(G.eval_flops(g, variant, args.classes, T, F, n_tr, n_va, args.epochs, 1) for g in genes) * args.steps
+        if roofline is not None:   # chip-level view: all algorithmic conv/dense FLOPs of the step / wall time
+            roofline["aggregate_timed_region"] = {"achieved": round(work / elapsed / 1e12, 2),
+                                                  "frac": round(work / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
         line = {
             "metric": "candidate-net evals/hour (pop=40, GSC-v2)", "value": round(value, 2), "unit": "candidate-evals/hour",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 2),

@@ -453,7 +453,7 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
 template <int BCO, int BKI>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                           float* __restrict__ P, GeomDev g, int rows_per_slice,
-                                                          float* __restrict__ Pbias) {
+                                                          float* __restrict__ Pbias, size_t slab_stride) {
     constexpr int MC = 32;
     constexpr int LDX = BKI + 16;                          // == 16 mod 32
     constexpr int LDY = (BCO == 16) ? 16 : BCO + 16;
@@ -573,10 +573,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
             const int q4 = t >> 2, j = t & 3;
             float sacc = 0.f;
             for (int r = 0; r < RPPY; ++r) sacc += red[4 * (r * TPRY + q4) + j];
-            Pbias[(size_t)blockIdx.z * g.Cout + co0 + t] = sacc;
+            Pbias[(size_t)blockIdx.z * slab_stride + co0 + t] = sacc;
         }
     }
-    float* Pout = P + (size_t)blockIdx.z * g.Cout * g.K;
+    float* Pout = P + (size_t)blockIdx.z * slab_stride;
 #pragma unroll
     for (int c2 = 0; c2 < CPW; ++c2)
 #pragma unroll
@@ -624,9 +624,10 @@ int wgrad_slices(const ConvGeom& g) {
 }
 
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s,
-                       const GemmTiming* tm, float* Pbias) {
+                       const GemmTiming* tm, float* Pbias, size_t slab_stride) {
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
+    const size_t stride = slab_stride ? slab_stride : (size_t)g.Cout * g.K;
     int rps = cdiv(g.M, S);
     rps = cdiv(rps, 32) * 32;
     const int N = g.Cout;
@@ -636,10 +637,10 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
 #define CMOOP_WG2(BCO_, BKI_)                                                                                   \
     do {                                                                                                       \
         if (tm && tm->start && tm->ext) {                                                                      \
-            hipExtLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps, Pbias); \
+            hipExtLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps, Pbias, stride); \
         } else {                                                                                               \
             if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));                                      \
-            hipLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, X, dY, P, g, rps, Pbias); \
+            hipLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, X, dY, P, g, rps, Pbias, stride); \
             if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));                                       \
         }                                                                                                      \
     } while (0)
@@ -660,21 +661,21 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
 
 // out[i] = sum_s P[s][i]: 64 elements x 4 slice lanes per block, fixed summation order
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ P, float* __restrict__ out, int S,
-                                                            int64_t n) {
+                                                            int64_t n, int64_t stride) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + e;
     float acc = 0.f;
     if (i < n)
-        for (int s = sl; s < S; s += 4) acc += P[(size_t)s * n + i];
+        for (int s = sl; s < S; s += 4) acc += P[(size_t)s * stride + i];
     red[sl][e] = acc;
     __syncthreads();
     if (sl == 0 && i < n) out[i] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
 }
 
-void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s) {
+void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s, int64_t stride) {
     if (n == 0) return;
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, P, out, S, n);
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, P, out, S, n, stride ? stride : n);
     CMOOP_HIP(hipGetLastError());
 }
 

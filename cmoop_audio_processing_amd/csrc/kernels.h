@@ -52,10 +52,12 @@ size_t igemm_splitk_workspace(const ConvGeom& g);
 int wgrad_slices(const ConvGeom& g);
 // returns the instantiation code BCO of the kernel that was launched
 // Pbias (optional): [S][N] per-slice column sums of dY (the bias gradient), fused into the first K tile's blocks
+// slab_stride: floats between consecutive slices of P and of Pbias (0 = N*K, bias slabs packed [S][N]);
+// the trainer lays slices out as [S][N*K + N] so one reduction yields kernel and bias gradients.
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& g, int S, hipStream_t s,
-                       const GemmTiming* tm = nullptr, float* Pbias = nullptr);
+                       const GemmTiming* tm = nullptr, float* Pbias = nullptr, size_t slab_stride = 0);
 // out[i] = sum_s P[s][i]  (fixed order -> deterministic)
-void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s);
+void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s, int64_t stride = 0);
 // Wd[ci][KH-1-kh][KW-1-kw][co] = W[co][kh][kw][ci]   (operand of the dgrad implicit GEMM)
 void launch_flip_transpose(const float* W, float* Wd, int Cout, int KH, int KW, int Cin, hipStream_t s);
 

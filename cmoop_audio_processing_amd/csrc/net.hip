@@ -353,15 +353,22 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
                            float* red_ws, hipStream_t s, GemmHook* hook) {
     const int M = g.M(), N = g.Cout, K = g.K();
     const int S = wgrad_slices(g);
-    // one slice (dense layers, deep convs): the kernel writes the gradients in place
-    float* Pk = S == 1 ? dW : wgrad_ws;
-    float* Pbias = S == 1 ? dB : wgrad_ws + (size_t)S * N * K;      // [S][N] right after the kernel-gradient slabs
+    // slices are laid out [S][N*K + N] (kernel partials then bias partials): when dB directly follows dW
+    // (the trainer's arena) a single fixed-order reduction produces both; one slice writes in place.
+    const size_t NK = (size_t)N * K, stride = NK + N;
+    const bool in_place = S == 1;
+    float* Pk = in_place ? dW : wgrad_ws;
+    float* Pbias = in_place ? dB : wgrad_ws + NK;
     const GemmTiming* tm = hook ? hook->begin(1, 2.0 * M * (double)N * K) : nullptr;
-    const int code = launch_igemm_wgrad(X, dY, Pk, g, S, s, tm, Pbias);
+    const int code = launch_igemm_wgrad(X, dY, Pk, g, S, s, tm, Pbias, in_place ? NK : stride);
     if (hook) hook->end(code);
-    if (S > 1) {
-        launch_reduce_slices(wgrad_ws, dW, S, (int64_t)N * K, s);
-        launch_reduce_slices(Pbias, dB, S, N, s);
+    if (!in_place) {
+        if (dB == dW + NK) {
+            launch_reduce_slices(wgrad_ws, dW, S, (int64_t)stride, s, (int64_t)stride);
+        } else {
+            launch_reduce_slices(wgrad_ws, dW, S, (int64_t)NK, s, (int64_t)stride);
+            launch_reduce_slices(wgrad_ws + NK, dB, S, N, s, (int64_t)stride);
+        }
     }
     (void)red_ws;
 }

@@ -52,7 +52,7 @@ class EvalConfig:
     max_model_size: float = 2.5   # MAX_MODEL_SIZE
     max_fpr: float = 0.1          # MAX_FPR
     seed: int = 0                 # the reference seeds nothing; the build makes runs reproducible
-    n_slots: int = 4              # candidates in flight per GPU
+    n_slots: int = 8              # candidates in flight per GPU (each on its own HIP stream)
     eval_batch: int = 256
     profile_every: int = 0
     lr: float = 1e-3
