@@ -215,3 +215,20 @@ def test_bad_inputs_fail_loudly():
         ev.evaluate_individual({"filters": 16})
     with pytest.raises(_lib.CmoopError):
         NetSession((16, 3, 0, 1, 1, 0), EvalConfig(classes=1), 21, 12, 0)
+
+
+def test_nsga2_pop4_gen2_on_gpu_config0():
+    """BASELINE configs[0] plumbing: the constrained NSGA-II loop (host) driving the GPU evaluator,
+    pop=4, gen=2 -> 4*(1+2) = 12 true evaluations; sharded_map path is the single-rank one here."""
+    from cmoop_audio_processing_amd import nsga
+    cfg = EvalConfig.preset("nsga_penalty", epochs=3, patience=1, batch=32, eval_batch=64, seed=1, n_slots=4)
+    Xtr, ytr = make_data(128, 21, 12, 10, 41)
+    Xva, yva = make_data(64, 21, 12, 10, 42)
+    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+    pareto, hist = nsga.nsga2(ev.compute_objectives_and_constraints, 4, 2, seed=0)
+    assert ev.evals_done == 12 and len(hist) == 2 and all(len(h) == 4 for h in hist)
+    for rec in hist[-1]:
+        assert rec["Size_MB"] == G.model_size_mb(G.normalize_hparams(rec), 0, 10)
+    fronts = [[ind["objs"] for ind in fake] for fake in ([{"objs": [-r["Accuracy"], r["Size_MB"], r["FPR"]]} for r in h] for h in hist)]
+    ref = nsga.shared_reference_point(fronts)
+    assert all(nsga.hypervolume(f, ref) > 0 for f in fronts)
