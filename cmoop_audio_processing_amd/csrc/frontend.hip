@@ -4,12 +4,16 @@
 // algorithm restates librosa.feature.melspectrogram (requirements.txt:80) and is
 // checked against oracle/frontend.py.
 //
-// One 256-thread workgroup per clip.  The whole 1 s clip (64 KB) is read from HBM
-// once with coalesced float4 loads into LDS; the twiddle table, the window and the
-// sparse mel weights are LDS-resident too, so each clip costs 64 000 B in and
-// T*n_mels*4 B out of HBM traffic.  Each wave owns one frame at a time.
+// One 256-thread workgroup per clip, each wave owns one frame at a time.  A frame is one
+// coalesced 2 KB segment of the clip; the 3.2x overlap between consecutive frames is served
+// by L2, so HBM sees each clip once (64 000 B in, T*n_mels*4 B out).  The twiddle table, the
+// window and the sparse mel weights are LDS-resident; each wave runs its radix-2 FFT in its
+// own LDS scratch with wave-level synchronisation only (25 KB LDS per workgroup, 6 per CU).
+// Measured 10.3 ms for 30 000 clips = 234 GB/s algorithmic (3 % of the HBM roofline): the
+// radix-2 LDS FFT, not HBM, bounds it; it runs once per dataset.
 #include "kernels.h"
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace cmoop {
@@ -94,6 +98,15 @@ void frontend_tables_destroy(FrontendTables* t) {
 
 constexpr int NFFT = 512, LOG2N = 9, MAXCLIP = 16384;
 
+// Each wave owns its re/im scratch, so the FFT stages only need the wave's own LDS writes to be
+// visible to its other lanes: LDS operations of one wave complete in issue order; the fences only
+// stop the compiler from moving the reads above the writes.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool CLIP_IN_LDS>
 __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wav, int n_samples, float* __restrict__ out,
                                                      int T, int hop, int n_mels, float log_eps,
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                 im[r] = 0.f;
             }
         }
-        __syncthreads();
+        wave_sync();
 #pragma unroll 1
         for (int s = 0; s < LOG2N; ++s) {
             if (live) {
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                     re[i1] = ar - tr; im[i1] = ai - ti;
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
         // power spectrum in place (bins 0..256 kept in re[])
         if (live) {
@@ -172,14 +185,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                 if (b <= NFFT / 2) re[b] = re[b] * re[b] + im[b] * im[b];
             }
         }
-        __syncthreads();
+        wave_sync();
         if (live && lane < n_mels) {
             const int first = s_off[2 * lane], cnt = s_off[2 * lane + 1], wo = s_off[2 * n_mels + lane];
             float acc = 0.f;
             for (int i = 0; i < cnt; ++i) acc = fmaf(s_melw[wo + i], re[first + i], acc);
             out[((size_t)blockIdx.x * T + frame) * n_mels + lane] = logf(acc + log_eps);
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -188,7 +201,11 @@ void launch_logmel(const float* wav, int64_t n_clips, int n_samples, float* out,
     const FrontendCfg& c = t->cfg;
     const int T = 1 + n_samples / c.hop;
     const size_t fixed = (NFFT + NFFT + 1024 + 8 * NFFT) * 4 + 192 * 4;
-    const bool in_lds = n_samples <= MAXCLIP && (n_samples % 4 == 0);
+    // default: frames are read straight from global memory (each 2 KB frame is one coalesced segment and the
+    // 3.2x overlap between frames is served by L2), leaving 25 KB of LDS per workgroup = 6 workgroups per CU;
+    // CMOOP_FE_CLIP_LDS=1 stages the whole clip in LDS instead (1 workgroup per CU)
+    const char* fe = std::getenv("CMOOP_FE_CLIP_LDS");
+    const bool in_lds = fe && fe[0] == '1' && n_samples <= MAXCLIP && (n_samples % 4 == 0);
     if (in_lds) {
         const size_t lds = fixed + (size_t)n_samples * 4;
         static bool attr_set = false;

@@ -232,3 +232,36 @@ def test_nsga2_pop4_gen2_on_gpu_config0():
     fronts = [[ind["objs"] for ind in fake] for fake in ([{"objs": [-r["Accuracy"], r["Size_MB"], r["FPR"]]} for r in h] for h in hist)]
     ref = nsga.shared_reference_point(fronts)
     assert all(nsga.hypervolume(f, ref) > 0 for f in fronts)
+
+
+def test_hypervolume_parity_gpu_vs_oracle_search():
+    """North-star gate 'hypervolume within 1 % of reference at equal generation count', at a scale the
+    CPU oracle finishes in about a minute: the same seeded NSGA-II search (pop 4, 2 generations, 3 epochs,
+    early stopping on) driven once by the GPU evaluator and once by the oracle; one shared reference point."""
+    from cmoop_audio_processing_amd import nsga
+    cfg = EvalConfig.preset("nsga_penalty", epochs=3, patience=2, batch=32, eval_batch=64, seed=7, n_slots=4)
+    Xtr, ytr = make_data(96, 21, 12, 10, 51)
+    Xva, yva = make_data(64, 21, 12, 10, 52)
+    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+    _, hist_gpu = nsga.nsga2(ev.compute_objectives_and_constraints, 4, 2, seed=2)
+
+    counter = {"n": 0}
+
+    def oracle_eval(pop):
+        out = []
+        for hp in pop:
+            g = G.normalize_hparams(hp)
+            acc, size, fpr, _ = ON.evaluate_individual(g, ocfg(cfg), Xtr, ytr, Xva, yva, seed=cfg.seed + counter["n"])
+            counter["n"] += 1
+            out.append(OM.assemble(hp, acc, size, fpr, cfg.min_accuracy, cfg.max_model_size, cfg.max_fpr))
+        return out
+    _, hist_cpu = nsga.nsga2(oracle_eval, 4, 2, seed=2)
+    f_gpu = [[[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in h] for h in hist_gpu]
+    f_cpu = [[[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in h] for h in hist_cpu]
+    ref = nsga.shared_reference_point(f_gpu + f_cpu)
+    for g in range(2):
+        # same genes survive in both searches (size is a pure function of the genes)
+        assert sorted(r["Size_MB"] for r in hist_gpu[g]) == sorted(r["Size_MB"] for r in hist_cpu[g])
+        hv_g, hv_c = nsga.hypervolume(f_gpu[g], ref), nsga.hypervolume(f_cpu[g], ref)
+        print(f"gen {g}: HV gpu {hv_g:.6f} oracle {hv_c:.6f}")
+        assert abs(hv_g - hv_c) <= 0.01 * max(hv_c, 1e-12)
