@@ -19,6 +19,8 @@ Fixtures (inputs + expected outputs of the reference functions):
                           get_lambda (nsga_penalty.py:217-219, sa_nsga_penalty.py:130-132)
   nsga_ops_golden.json    dominates / fast_non_dominated_sort / crowding_distance
                           (nsga_penalty.py:448-524) -- for the host-loop row N1 (next)
+  surrogate_golden.json   SurrogateManager (sa_nsga_local.py:169-234) + select_infill_points
+                          (sa_nsga_penalty.py:472-518) under a fixed numpy seed -- row N2
 """
 import ast
 import json
@@ -39,12 +41,12 @@ def extract(path, names, extra_globals=None, assigns=()):
     tree = ast.parse(src)
     body = []
     for node in tree.body:
-        if isinstance(node, ast.FunctionDef) and node.name in names:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names:
             body.append(node)
         elif isinstance(node, ast.Assign) and len(node.targets) == 1 and \
                 isinstance(node.targets[0], ast.Name) and node.targets[0].id in assigns:
             body.append(node)
-    found = {n.name for n in body if isinstance(n, ast.FunctionDef)}
+    found = {n.name for n in body if isinstance(n, (ast.FunctionDef, ast.ClassDef))}
     missing = set(names) - found
     if missing:
         raise SystemExit(f"{path}: functions not found: {missing}")
@@ -178,6 +180,67 @@ def gen_nsga_ops():
     print("nsga_ops_golden.json", len(cases), "cases")
 
 
+def gen_surrogate():
+    """SurrogateManager (sa_nsga_local.py:169-234, the return_std variant) and select_infill_points
+    (sa_nsga_penalty.py:472-518) under a fixed numpy seed (the GPs draw their optimiser restarts from
+    numpy's global RNG)."""
+    import pandas as pd
+    from copy import deepcopy
+    from sklearn.compose import ColumnTransformer
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import ConstantKernel as C, Matern, WhiteKernel
+    from sklearn.preprocessing import OneHotEncoder, StandardScaler
+    env = dict(pd=pd, deepcopy=deepcopy, ColumnTransformer=ColumnTransformer, GaussianProcessRegressor=GaussianProcessRegressor,
+               C=C, Matern=Matern, WhiteKernel=WhiteKernel, OneHotEncoder=OneHotEncoder, StandardScaler=StandardScaler, EPSILON=1e-6)
+    SM = extract("ablation_study/sa_nsga_local.py", ["SurrogateManager"], env)["SurrogateManager"]
+    infill = extract("sa_nsga_penalty.py", ["select_infill_points"], dict(EPSILON=1e-6))["select_infill_points"]
+    rnd = random.Random(42)
+
+    def hp():
+        return {"filters": rnd.choice([16, 32, 64]), "kernel_size": rnd.choice([3, 5]), "use_bn": rnd.choice([True, False]),
+                "residual_blocks": rnd.choice([1, 2, 3]), "fc_layers": rnd.choice([1, 2, 3, 4]), "use_dropout": rnd.choice([True, False])}
+
+    def res(h):
+        acc = 0.7 + 0.03 * h["residual_blocks"] + 0.01 * h["fc_layers"] + (0.04 if h["use_bn"] else 0) + 0.0007 * h["filters"] + rnd.uniform(-0.02, 0.02)
+        size = 0.05 * h["filters"] / 16 * h["kernel_size"] ** 2 / 9 * 2 ** h["residual_blocks"]
+        fpr = 0.2 - 0.15 * acc + rnd.uniform(0, 0.01)
+        cv = max(0.0, 0.9 - acc) + max(0.0, size - 2.5) + max(0.0, fpr - 0.09)
+        return {"hparams": h, "objs": [-acc, size, fpr], "CV": cv}
+    train1 = [hp() for _ in range(12)]
+    res1 = [res(h) for h in train1]
+    train2 = [hp() for _ in range(2)] + [dict(train1[3])]            # one duplicate genotype: keep='last'
+    res2 = [res(h) for h in train2]
+    query = [hp() for _ in range(16)]
+    sm = SM()
+    np.random.seed(123)
+    sm.update(train1, res1)
+    p1, s1 = sm.predict(query, return_std=True)
+    struct1 = sm.predict_and_structure(query)
+    idx, _ = infill(struct1, 5)
+    np.random.seed(124)
+    sm.update(train2, res2)
+    p2, s2 = sm.predict(query, return_std=True)
+
+    def tolist(d):
+        return {k: [float(x) for x in v] for k, v in d.items()}
+    out = {"train1": train1, "res1": [{"objs": r["objs"], "CV": r["CV"]} for r in res1],
+           "train2": train2, "res2": [{"objs": r["objs"], "CV": r["CV"]} for r in res2], "query": query,
+           "seed1": 123, "seed2": 124, "pred1": tolist(p1), "std1": tolist(s1), "pred2": tolist(p2), "std2": tolist(s2),
+           "structured1": [{"objs": [float(v) for v in r["objs"]], "CV": float(r["CV"])} for r in struct1],
+           "infill_indices_top5": [int(i) for i in idx], "n_training_rows_after_update2": int(len(sm.training_data))}
+    # select_infill_points on hand-made predicted sets (feasible-first, normalised-sum score, CV ranking)
+    rs = np.random.RandomState(8)
+    sel_cases = []
+    for n, k in ((6, 2), (15, 3), (15, 20), (4, 1)):
+        pred = [{"hparams": {"id": i}, "objs": [float(-rs.uniform(0.6, 0.95)), float(rs.uniform(0.05, 3)), float(rs.uniform(0, 0.2))],
+                 "CV": float(rs.choice([0.0, 0.0, rs.uniform(0, 0.4)]))} for i in range(n)]
+        ii, hh = infill(pred, k)
+        sel_cases.append({"predicted": pred, "k": k, "indices": [int(i) for i in ii]})
+    out["select_cases"] = sel_cases
+    json.dump(out, open(os.path.join(OUT, "surrogate_golden.json"), "w"))
+    print("surrogate_golden.json", len(query), "queries,", len(sel_cases), "selection cases")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -185,3 +248,4 @@ if __name__ == "__main__":
     gen_objectives()
     gen_codec()
     gen_nsga_ops()
+    gen_surrogate()
