@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--weak", action="store_true", help="population = pop * gpus")
     ap.add_argument("--profile-every", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --same-device rehearses N ranks on one GPU")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (single-GPU rehearsal of the N>1 path)")
     args = ap.parse_args()
 
     # under rocprofv3 the tool library crashes on hipExtLaunchKernelGGL (ROCm 7.2): fall back to plain
@@ -133,10 +135,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -197,7 +204,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

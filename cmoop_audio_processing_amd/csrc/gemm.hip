@@ -8,6 +8,7 @@
 // so the order of summation inside a 16-k group is a fixed permutation).
 #include "kernels.h"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 #include <mutex>
 
 namespace cmoop {
@@ -29,6 +30,18 @@ struct EpiDev {
     uint32_t drop_prefix, drop_thr;
     float drop_scale;
 };
+
+// CMOOP_PAR_SCALE (default 1): scales how many workgroups a single GEMM launch aims for.  With several
+// candidates in flight the streams fill the chip together, so fewer K-splits / row slices (less slab
+// traffic, fewer combine passes) can win; 1.0 sizes every launch to fill the chip alone.
+static double par_scale() {
+    static const double v = [] {
+        const char* e = std::getenv("CMOOP_PAR_SCALE");
+        const double x = e ? std::atof(e) : 1.0;
+        return x > 0.01 && x <= 4.0 ? x : 1.0;
+    }();
+    return v;
+}
 
 // Granlund-Montgomery division by an invariant: q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
 static void fastdiv_init(int d, uint32_t* magic, uint32_t* shift) {
@@ -381,14 +394,15 @@ static void pick_tile(int M, int N, int K, int bk, size_t ws_floats, int* bm, in
     const int bn_big = N > 64 ? 128 : bn_small;
     *splits = 1;
     long blocks = (long)cdiv(M, 128) * cdiv(N, bn_big);
-    if (blocks >= 384) { *bm = 128; *bn = bn_big; return; }
+    const long fill = std::max(32l, (long)(384 * par_scale()));
+    if (blocks >= fill) { *bm = 128; *bn = bn_big; return; }
     const int nchunks = cdiv(K, bk);
     if (nchunks >= (M <= 512 ? 4 : 16) && ws_floats > 0) {
         // dense layers (M = batch rows) are a serial latency chain of K chunks: split them finely
         const int min_chunks = M <= 512 ? 2 : 8;
-        int sp = (int)std::min<long>(cdiv(1024, (int)blocks), nchunks / min_chunks);
+        int sp = (int)std::min<long>(cdiv((int)(1024 * par_scale()), (int)blocks), nchunks / min_chunks);
         sp = std::min(sp, 32);
-        if (sp > 1) sp = fill_waves(blocks, sp, 512);
+        if (sp > 1) sp = fill_waves(blocks, sp, std::max(32, (int)(512 * par_scale())));
         while (sp > 1 && (size_t)sp * M * N > ws_floats) --sp;
         if (sp > 1) {
             const int cps = cdiv(nchunks, sp);
@@ -398,7 +412,7 @@ static void pick_tile(int M, int N, int K, int bk, size_t ws_floats, int* bm, in
         }
     }
     blocks = (long)cdiv(M, 128) * cdiv(N, bn_small);
-    if (blocks >= 384) { *bm = 128; *bn = bn_small; return; }
+    if (blocks >= fill) { *bm = 128; *bn = bn_small; return; }
     *bm = 64; *bn = bn_small;
 }
 
@@ -607,7 +621,7 @@ int wgrad_slices(const ConvGeom& g) {
     const int M = g.M(), K = g.K(), N = g.Cout;
     const int bco = wgrad_bco(N);
     const int tiles = cdiv(K, wgrad_bki(M, N, K)) * cdiv(N, bco);
-    int S = cdiv(2048, tiles);
+    int S = cdiv((int)(2048 * par_scale()), tiles);
     // cap the slab traffic (S*N*K floats written and read back): at most ~16M floats, but keep >= 8 slices
     const int64_t nk = (int64_t)N * K;
     const int cap = (int)std::max<int64_t>(8, (16ll << 20) / std::max<int64_t>(nk, 1));
@@ -618,7 +632,7 @@ int wgrad_slices(const ConvGeom& g) {
     // (LDS-limited occupancy of each instantiation: 160 KiB / LDS per workgroup)
     const int bki = wgrad_bki(M, N, K);
     const int lds_bytes = 2 * 32 * ((bki + 16) + (bco == 16 ? 16 : bco + 16)) * 4;
-    const int resident = 256 * std::max(1, std::min(8, (160 * 1024) / lds_bytes));
+    const int resident = std::max(32, (int)(par_scale() * 256 * std::max(1, std::min(8, (160 * 1024) / lds_bytes))));
     if ((long)tiles * S < 4l * resident) S = fill_waves(tiles, S, resident);
     const int maxS = std::max(1, M / 256);
     if (S > maxS) S = maxS;

@@ -138,6 +138,8 @@ def sharded_map(local_fn: Callable[[List[int]], np.ndarray], costs: Sequence[flo
         return np.asarray(local_fn(list(range(n))), dtype=np.float64).reshape(n, width)
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
+    if str(dist.get_backend()).lower() == "gloo":
+        device = "cpu"            # CPU rehearsals (tests, single-GPU boxes); RCCL ("nccl") exchanges device tensors
     buckets = G.lpt_assign(costs, world)
     slots = max(1, max(len(b) for b in buckets))
     mine = buckets[rank]
