@@ -19,6 +19,8 @@ Fixtures (inputs + expected outputs of the reference functions):
                           get_lambda (nsga_penalty.py:217-219, sa_nsga_penalty.py:130-132)
   nsga_ops_golden.json    dominates / fast_non_dominated_sort / crowding_distance
                           (nsga_penalty.py:448-524) -- for the host-loop row N1 (next)
+  metrics_golden.json     GD / IGD / Spread / C-metric (compare.ipynb) and the Tchebycheff score/rank
+                          ("Tchebycheff s_rank.ipynb") -- row N3
   surrogate_golden.json   SurrogateManager (sa_nsga_local.py:169-234) + select_infill_points
                           (sa_nsga_penalty.py:472-518) under a fixed numpy seed -- row N2
 """
@@ -241,6 +243,58 @@ def gen_surrogate():
     print("surrogate_golden.json", len(query), "queries,", len(sel_cases), "selection cases")
 
 
+def gen_metrics():
+    """GD / IGD / Spread / C-metric / true front from compare.ipynb (cell 0) and the Tchebycheff score from
+    'Tchebycheff s_rank.ipynb': the notebooks' FunctionDefs only, executed on random fronts."""
+    from scipy.spatial.distance import cdist
+    import pandas as pd
+
+    def nb_funcs(path, names):
+        nb = json.load(open(os.path.join(REF, path)))
+        body = []
+        for c in nb["cells"]:
+            if c["cell_type"] != "code":
+                continue
+            src = "".join(c["source"])
+            try:
+                tree = ast.parse(src)
+            except SyntaxError:
+                continue
+            body += [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+        ns = {"np": np, "cdist": cdist}
+        exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+        return ns
+    f = nb_funcs("compare.ipynb", ["dominates_min", "generational_distance", "inverted_gd", "spread_metric", "coverage_metric"])
+    t = nb_funcs("Tchebycheff s_rank.ipynb", ["tchebycheff_score"])
+    rs = np.random.RandomState(21)
+    cases = []
+    for na, nb_ in ((5, 7), (12, 3), (1, 4), (9, 9)):
+        A = np.c_[-rs.uniform(0.85, 0.95, na), rs.uniform(0.05, 2.4, na), rs.uniform(0.005, 0.02, na)]
+        B = np.c_[-rs.uniform(0.85, 0.95, nb_), rs.uniform(0.05, 2.4, nb_), rs.uniform(0.005, 0.02, nb_)]
+        allp = np.vstack([A, B])
+        mask = np.ones(len(allp), bool)
+        for i in range(len(allp)):
+            for j in range(len(allp)):
+                if i != j and f["dominates_min"](allp[j], allp[i]):
+                    mask[i] = False
+                    break
+        tf = allp[mask]
+        sp = f["spread_metric"](A, tf)
+        cases.append({"A": A.tolist(), "B": B.tolist(), "true_front": tf.tolist(),
+                      "gd": jf(f["generational_distance"](A, tf)), "igd": jf(f["inverted_gd"](A, tf)),
+                      "spread": None if np.isnan(sp) else jf(sp), "c_ab": jf(f["coverage_metric"](A, B)),
+                      "c_ba": jf(f["coverage_metric"](B, A))})
+    acc, size, fpr = rs.uniform(0.85, 0.95, 10), rs.uniform(0.05, 2.4, 10), rs.uniform(0.005, 0.02, 10)
+    acc[3], size[3], fpr[3] = acc[7], size[7], fpr[7]                       # a tie
+    F = np.column_stack([1.0 - acc, size, fpr])
+    sc = t["tchebycheff_score"](F, F.min(axis=0), np.ones(3) / 3.0)
+    ranks = pd.Series(sc).rank(method="min", ascending=True).astype(int).tolist()
+    json.dump({"cases": cases, "tcheby": {"acc": acc.tolist(), "size": size.tolist(), "fpr": fpr.tolist(),
+                                          "scores": [jf(v) for v in sc], "ranks": ranks}},
+              open(os.path.join(OUT, "metrics_golden.json"), "w"))
+    print("metrics_golden.json", len(cases), "cases")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -249,3 +303,4 @@ if __name__ == "__main__":
     gen_codec()
     gen_nsga_ops()
     gen_surrogate()
+    gen_metrics()
