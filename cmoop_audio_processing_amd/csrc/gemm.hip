@@ -10,10 +10,48 @@
 #include <hip/hip_ext.h>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 
 namespace cmoop {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// OPT-IN "bf16x3" mode (CMOOP_GEMM_MODE=bf16x3): every fp32 operand is split EXACTLY into three bf16
+// values by truncation (a = a0 + a1 + a2, 8+8+8 mantissa bits) and a product is evaluated as the six
+// bf16 MFMA terms a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0 accumulated in fp32 (dropped terms < 2^-24
+// relative).  v_mfma_f32_16x16x32_bf16 runs at 16x the fp32 MFMA rate, so six of them still cost 2.7x less
+// pipe time than the eight exact-fp32 MFMAs they replace.  NOT the default: results are fp32-accurate
+// (same parity tolerances) but not the bit-exact fmaf chain of the fp32 MFMA.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    u32x4 w0, w1, w2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = i < 2 ? lo[2 * i] : hi[2 * i - 4], y = i < 2 ? lo[2 * i + 1] : hi[2 * i - 3];
+        const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+        w0[i] = (uy & 0xFFFF0000u) | (ux >> 16);
+        const float rx = x - __uint_as_float(ux & 0xFFFF0000u), ry = y - __uint_as_float(uy & 0xFFFF0000u);
+        const unsigned vx = __float_as_uint(rx), vy = __float_as_uint(ry);
+        w1[i] = (vy & 0xFFFF0000u) | (vx >> 16);
+        const float sx = rx - __uint_as_float(vx & 0xFFFF0000u), sy = ry - __uint_as_float(vy & 0xFFFF0000u);
+        w2[i] = (__float_as_uint(sy) & 0xFFFF0000u) | (__float_as_uint(sx) >> 16);
+    }
+    p0 = __builtin_bit_cast(bf16x8, w0);
+    p1 = __builtin_bit_cast(bf16x8, w1);
+    p2 = __builtin_bit_cast(bf16x8, w2);
+}
+
+static bool gemm_mode_x3() {
+    static const bool v = [] {
+        const char* e = std::getenv("CMOOP_GEMM_MODE");
+        return e && std::string(e) == "bf16x3";
+    }();
+    return v;
+}
 
 struct GeomDev {
     int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad_t, pad_l;
@@ -97,7 +135,7 @@ static GeomDev to_dev(const ConvGeom& g) {
 // RT x CT MFMA tiles of 16x16.  Tile shape is picked per layer so that the grid
 // fills the 256 CUs (small-spatial deep layers use 64-row tiles).
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int BK, int WM>
+template <int BM, int BN, int BK, int WM, bool X3 = false>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                         float* __restrict__ Y, GeomDev g, EpiDev e,
                                                         float* __restrict__ slab, int chunks_per_split) {
@@ -187,6 +225,37 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
+        if constexpr (X3) {
+            // one 16x16x32 bf16 k-step per 32-deep chunk; lane (lr, q) holds k = 8q..8q+7 of its row
+            static_assert(!X3 || BK == 32, "bf16x3 path needs 32-deep K chunks");
+            bf16x8 a0[RT], a1[RT], a2[RT], b0[CT], b1[CT], b2[CT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float* pa = &As[buf][(wrow + rt * 16 + lr) * LDK + q * 8];
+                split8(*reinterpret_cast<const f32x4*>(pa), *reinterpret_cast<const f32x4*>(pa + 4), a0[rt], a1[rt], a2[rt]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float* pb = &Bs[buf][(wcol + ct * 16 + lr) * LDK + q * 8];
+                split8(*reinterpret_cast<const f32x4*>(pb), *reinterpret_cast<const f32x4*>(pb + 4), b0[ct], b1[ct], b2[ct]);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    f32x4 c = acc[rt][ct];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[rt], b0[ct], c, 0, 0, 0);   // small terms first
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[rt], b1[ct], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b2[ct], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[rt], b0[ct], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b1[ct], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b0[ct], c, 0, 0, 0);
+                    acc[rt][ct] = c;
+                }
+            __builtin_amdgcn_s_setprio(0);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             f32x4 a[RT], b[CT];
@@ -341,7 +410,7 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
     }
 }
 
-template <int BM, int BN, int BK, int WM>
+template <int BM, int BN, int BK, int WM, bool X3 = false>
 static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDev& g, const EpiDev& e, hipStream_t s,
                          const GemmTiming* tm, float* slab, int splits) {
     dim3 grid(cdiv(g.M, BM), cdiv(g.Cout, BN), splits);
@@ -349,11 +418,11 @@ static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDe
     const int cps = cdiv(nchunks, splits);
     float* sl = splits > 1 ? slab : nullptr;
     if (tm && tm->start && tm->ext) {
-        hipExtLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, Wt, Y, g, e,
-                              sl, cps);
+        hipExtLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM, X3>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, Wt, Y, g,
+                              e, sl, cps);
     } else {
         if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));
-        hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM>), grid, dim3(256), 0, s, X, Wt, Y, g, e, sl, cps);
+        hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM, X3>), grid, dim3(256), 0, s, X, Wt, Y, g, e, sl, cps);
         if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));
     }
     CMOOP_HIP(hipGetLastError());
@@ -441,10 +510,12 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     pick_tile(g.M, g.Cout, g.K, bk32 ? 32 : 16, splitk_ws ? splitk_ws_floats : 0, &bm, &bn, &splits);
     // many-wave grids of 128x64 tiles run 3-4 % faster with 16-deep K chunks (half the LDS, 4-5 workgroups
     // per CU instead of 2); single-wave grids prefer the 32-deep chunk (half the barriers)
-    const bool bk32_tile = bk32 && !(bm == 128 && bn == 64 && splits == 1 && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024);
+    const bool x3 = bk32 && gemm_mode_x3();
+    const bool bk32_tile = x3 || (bk32 && !(bm == 128 && bn == 64 && splits == 1 && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024));
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \
     do {                                                                                      \
-        if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);   \
+        if (x3) launch_fwd_t<BM_, BN_, 32, WM_, true>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);     \
+        else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);   \
         else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);        \
     } while (0)
     if (bm == 128) {

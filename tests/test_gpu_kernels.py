@@ -213,3 +213,16 @@ def test_frontend_edge_cases():
         assert out.shape == (3, 1 + L // 160, 40)
         assert np.abs(out - ofe.log_mel(w)).max() < 2e-4
     assert fe.log_mel(torch.zeros((0, 16000), device="cuda")).shape == (0, 101, 40)
+
+
+def test_bf16x3_mode_meets_the_same_tolerance():
+    """The opt-in split-precision GEMM body (CMOOP_GEMM_MODE=bf16x3) is read once per process, so it is
+    exercised in a child process: conv fwd + bwd parity at the exact path's tolerances."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CMOOP_GEMM_MODE="bf16x3")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "test_conv_fwd or test_conv_bwd"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
