@@ -13,107 +13,140 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // first layer: C_in = 1 direct conv (Keras Conv2D(filters, k, padding='same') on
 // the (T,F,1) input, nsga_penalty.py:255 / sa_nsga_penalty.py:151)
 // ===========================================================================
+// Thread = 4 consecutive pixels of one row x 4 output channels: each input row segment (4 + KS - 1 values)
+// is loaded once and reused by the KS horizontal taps of all four pixels; weights come from LDS as float4.
+template <int KS>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx,
                                                         int64_t row0, const float* __restrict__ Wt,
                                                         const float* __restrict__ bias, float* __restrict__ Y, int B,
-                                                        int H, int W, int Cout, int KS, int relu) {
-    __shared__ __attribute__((aligned(16))) float Ws[25 * 64];
+                                                        int H, int W, int Cout, int relu) {
+    constexpr int TAPS = KS * KS, SEG = 4 + KS - 1, p = (KS - 1) >> 1;
+    __shared__ __attribute__((aligned(16))) float Ws[TAPS * 64];
     const int t = threadIdx.x;
-    const int taps = KS * KS;
-    for (int i = t; i < taps * Cout; i += 256) {
-        int co = i / taps, tap = i - co * taps;
+    for (int i = t; i < TAPS * Cout; i += 256) {
+        int co = i / TAPS, tap = i - co * TAPS;
         Ws[tap * Cout + co] = Wt[i];
     }
     __syncthreads();
-    const int TPP = Cout >> 2, PPB = 256 / TPP;
-    const int64_t pixel = (int64_t)blockIdx.x * PPB + t / TPP;
-    const int c4 = t % TPP;
-    const int HW = H * W;
-    if (pixel >= (int64_t)B * HW) return;
-    const int b = (int)(pixel / HW), r = (int)(pixel - (int64_t)b * HW);
-    const int h = r / W, w = r - h * W;
+    const int TPG = Cout >> 2, GPB = 256 / TPG;
+    const int W4 = (W + 3) >> 2;
+    const int64_t group = (int64_t)blockIdx.x * GPB + t / TPG;
+    const int c4 = t % TPG;
+    if (group >= (int64_t)B * H * W4) return;
+    const int b = (int)(group / (H * W4)), r = (int)(group - (int64_t)b * H * W4);
+    const int h = r / W4, w0 = (r - h * W4) * 4;
     const int64_t src = idx ? (int64_t)idx[row0 + b] : row0 + b;
-    const float* xb = X + src * HW;
-    const int p = (KS - 1) >> 1;
-    f32x4 acc = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
+    const float* xb = X + src * (int64_t)H * W;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
+    f32x4 acc[4] = {bv, bv, bv, bv};
+#pragma unroll
     for (int kh = 0; kh < KS; ++kh) {
         const int ih = h + kh - p;
         if ((unsigned)ih >= (unsigned)H) continue;
+        float xr[SEG];
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+            const int iw = w0 - p + j;
+            xr[j] = (unsigned)iw < (unsigned)W ? xb[ih * W + iw] : 0.f;
+        }
+#pragma unroll
         for (int kw = 0; kw < KS; ++kw) {
-            const int iw = w + kw - p;
-            if ((unsigned)iw >= (unsigned)W) continue;
-            const float xv = xb[ih * W + iw];
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Ws[(kh * KS + kw) * Cout + 4 * c4]);
-            acc[0] = fmaf(xv, w4[0], acc[0]); acc[1] = fmaf(xv, w4[1], acc[1]);
-            acc[2] = fmaf(xv, w4[2], acc[2]); acc[3] = fmaf(xv, w4[3], acc[3]);
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const float xv = xr[px + kw];
+                acc[px][0] = fmaf(xv, w4[0], acc[px][0]); acc[px][1] = fmaf(xv, w4[1], acc[px][1]);
+                acc[px][2] = fmaf(xv, w4[2], acc[px][2]); acc[px][3] = fmaf(xv, w4[3], acc[px][3]);
+            }
         }
     }
-    if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
-    *reinterpret_cast<f32x4*>(Y + pixel * Cout + 4 * c4) = acc;
+    const int64_t pix0 = ((int64_t)b * H + h) * W + w0;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+        if (w0 + px >= W) break;
+        f32x4 v = acc[px];
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<f32x4*>(Y + (pix0 + px) * Cout + 4 * c4) = v;
+    }
 }
 
 void launch_conv1_fwd(const float* X, const int32_t* idx, int64_t row0, const float* Wt, const float* bias, float* Y,
                       int B, int H, int W, int Cout, int KS, int relu, hipStream_t s) {
-    CMOOP_REQUIRE(Cout % 4 == 0 && Cout <= 64 && 64 % (Cout / 4) == 0 && KS * KS <= 25, "conv1: unsupported shape");
-    const int PPB = 256 / (Cout / 4);
-    const int64_t pixels = (int64_t)B * H * W;
-    if (pixels == 0) return;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)cdiv64(pixels, PPB)), dim3(256), 0, s, X, idx, row0, Wt, bias, Y,
-                       B, H, W, Cout, KS, relu);
+    CMOOP_REQUIRE(Cout % 4 == 0 && Cout <= 64 && 64 % (Cout / 4) == 0 && (KS == 3 || KS == 5), "conv1: unsupported shape");
+    const int GPB = 256 / (Cout / 4);
+    const int64_t groups = (int64_t)B * H * ((W + 3) / 4);
+    if (groups == 0) return;
+    const dim3 grid((unsigned)cdiv64(groups, GPB));
+    if (KS == 3) hipLaunchKernelGGL(conv1_fwd_kernel<3>, grid, dim3(256), 0, s, X, idx, row0, Wt, bias, Y, B, H, W, Cout, relu);
+    else hipLaunchKernelGGL(conv1_fwd_kernel<5>, grid, dim3(256), 0, s, X, idx, row0, Wt, bias, Y, B, H, W, Cout, relu);
     CMOOP_HIP(hipGetLastError());
 }
 
 int conv1_wgrad_blocks(int B, int H, int W) {
-    int64_t pixels = (int64_t)B * H * W;
-    return (int)std::max<int64_t>(1, std::min<int64_t>(512, pixels / 256));
+    int64_t groups = (int64_t)B * H * ((W + 3) / 4);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(512, groups / 64));
 }
 
 template <int KS>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx,
                                                           int64_t row0, const float* __restrict__ dY,
                                                           float* __restrict__ P, int B, int H, int W, int Cout) {
-    constexpr int TAPS = KS * KS;
+    constexpr int TAPS = KS * KS, SEG = 4 + KS - 1, p = (KS - 1) >> 1;
     __shared__ float red[4 * (TAPS + 1) * 64];
     const int t = threadIdx.x;
-    const int TPP = Cout >> 2, PPB = 256 / TPP;
-    const int pl = t / TPP, c4 = t % TPP;
-    const int HW = H * W;
-    const int64_t pixels = (int64_t)B * HW;
-    constexpr int p = (KS - 1) >> 1;
+    const int TPG = Cout >> 2, GPB = 256 / TPG;
+    const int gl = t / TPG, c4 = t % TPG;
+    const int W4 = (W + 3) >> 2;
+    const int64_t groups = (int64_t)B * H * W4;
     f32x4 acc[TAPS + 1];
 #pragma unroll
     for (int i = 0; i <= TAPS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int64_t pixel = (int64_t)blockIdx.x * PPB + pl; pixel < pixels; pixel += (int64_t)gridDim.x * PPB) {
-        const int b = (int)(pixel / HW), r = (int)(pixel - (int64_t)b * HW);
-        const int h = r / W, w = r - h * W;
+    for (int64_t group = (int64_t)blockIdx.x * GPB + gl; group < groups; group += (int64_t)gridDim.x * GPB) {
+        const int b = (int)(group / (H * W4)), r = (int)(group - (int64_t)b * H * W4);
+        const int h = r / W4, w0 = (r - h * W4) * 4;
         const int64_t src = idx ? (int64_t)idx[row0 + b] : row0 + b;
-        const float* xb = X + src * HW;
-        const f32x4 dy = *reinterpret_cast<const f32x4*>(dY + pixel * Cout + 4 * c4);
+        const float* xb = X + src * (int64_t)H * W;
+        const int64_t pix0 = ((int64_t)b * H + h) * W + w0;
+        f32x4 dy[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            dy[px] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (w0 + px < W) dy[px] = *reinterpret_cast<const f32x4*>(dY + (pix0 + px) * Cout + 4 * c4);
+            acc[TAPS] += dy[px];
+        }
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh) {
+            const int ih = h + kh - p;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            float xr[SEG];
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) {
+                const int iw = w0 - p + j;
+                xr[j] = (unsigned)iw < (unsigned)W ? xb[ih * W + iw] : 0.f;
+            }
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
-                const int ih = h + kh - p, iw = w + kw - p;
-                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-                const float xv = ok ? xb[ih * W + iw] : 0.f;
                 f32x4& a = acc[kh * KS + kw];
-                a[0] = fmaf(xv, dy[0], a[0]); a[1] = fmaf(xv, dy[1], a[1]);
-                a[2] = fmaf(xv, dy[2], a[2]); a[3] = fmaf(xv, dy[3], a[3]);
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    const float xv = xr[px + kw];
+                    a[0] = fmaf(xv, dy[px][0], a[0]); a[1] = fmaf(xv, dy[px][1], a[1]);
+                    a[2] = fmaf(xv, dy[px][2], a[2]); a[3] = fmaf(xv, dy[px][3], a[3]);
+                }
             }
         }
-        acc[TAPS] += dy;
     }
-    // lanes sharing c4 sit TPP apart inside the wave: butterfly down to TPP
+    // lanes sharing c4 sit TPG apart inside the wave: butterfly down to TPG
     const int lane = t & 63, wave = t >> 6;
 #pragma unroll
     for (int i = 0; i <= TAPS; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v = acc[i][j];
-            for (int off = 32; off >= TPP; off >>= 1) v += __shfl_xor(v, off, 64);
+            for (int off = 32; off >= TPG; off >>= 1) v += __shfl_xor(v, off, 64);
             acc[i][j] = v;
         }
-    if (lane < TPP) {
+    if (lane < TPG) {
 #pragma unroll
         for (int i = 0; i <= TAPS; ++i)
 #pragma unroll

@@ -747,23 +747,55 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     return bco * 1000 + bki;
 }
 
-// out[i] = sum_s P[s][i]: 64 elements x 4 slice lanes per block, fixed summation order
+// out[i] = sum_s P[s][i], fixed summation order.  Vector form: each thread owns one float4 column group,
+// 4 slice lanes x 4 independent accumulators keep 16 loads of 16 B in flight per thread.
+template <int VEC>
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ P, float* __restrict__ out, int S,
                                                             int64_t n, int64_t stride) {
-    __shared__ float red[4][64];
+    __shared__ float red[4][64 * VEC];
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + e;
-    float acc = 0.f;
-    if (i < n)
-        for (int s = sl; s < S; s += 4) acc += P[(size_t)s * stride + i];
-    red[sl][e] = acc;
+    const int64_t i = ((int64_t)blockIdx.x * 64 + e) * VEC;
+    float acc[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[u][j] = 0.f;
+    if (i < n) {
+        int s = sl;
+        for (; s + 12 < S; s += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* src = P + (size_t)(s + 4 * u) * stride + i;
+                if constexpr (VEC == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                    acc[u][0] += v[0]; acc[u][1] += v[1]; acc[u][2] += v[2]; acc[u][3] += v[3];
+                } else {
+                    acc[u][0] += src[0];
+                }
+            }
+        }
+        for (; s < S; s += 4) {
+            const float* src = P + (size_t)s * stride + i;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[0][j] += src[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[sl][e * VEC + j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
     __syncthreads();
-    if (sl == 0 && i < n) out[i] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    if (sl == 0 && i < n) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            out[i + j] = ((red[0][e * VEC + j] + red[1][e * VEC + j]) + red[2][e * VEC + j]) + red[3][e * VEC + j];
+    }
 }
 
 void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s, int64_t stride) {
     if (n == 0) return;
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, P, out, S, n, stride ? stride : n);
+    if (!stride) stride = n;
+    const bool vec = (n % 4 == 0) && (stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+    if (vec) hipLaunchKernelGGL(reduce_slices_kernel<4>, dim3((unsigned)cdiv64(n / 4, 64)), dim3(256), 0, s, P, out, S, n, stride);
+    else hipLaunchKernelGGL(reduce_slices_kernel<1>, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, P, out, S, n, stride);
     CMOOP_HIP(hipGetLastError());
 }
 
