@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--weak", action="store_true", help="population = pop * gpus")
     ap.add_argument("--profile-every", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-mode", default="fp32", choices=["fp32", "bf16x3", "bf16x3r"],
+                    help="fp32 = exact fp32 MFMA (the product path). bf16x3 = EXPERIMENTAL opt-in: forward/dgrad GEMMs split every "
+                         "fp32 operand exactly into three bf16 values and use six bf16 MFMA terms (fp32-accurate, not bit-exact)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --same-device rehearses N ranks on one GPU")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (single-GPU rehearsal of the N>1 path)")
     args = ap.parse_args()
@@ -127,6 +130,8 @@ def main():
     under_rocprof = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if under_rocprof:
         os.environ["CMOOP_PROFILE_PAIRS"] = "1"
+    if args.gemm_mode != "fp32":
+        os.environ["CMOOP_GEMM_MODE"] = args.gemm_mode      # read once by the library
 
     import torch
     import torch.distributed as dist
@@ -271,7 +276,8 @@ def main():
         line = {
             "metric": "candidate-net evals/hour (pop=40, GSC-v2)", "value": round(value, 2), "unit": "candidate-evals/hour",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
+            "dtype": "f32" if args.gemm_mode == "fp32" else f"f32 operands as 3 x bf16 ({args.gemm_mode}, EXPERIMENTAL, fwd/dgrad GEMMs only)",
             "data": "synthetic",
             "config": {"workload": f"pop={n_pop} gen=1 fitness eval (topology {args.variant}, {args.classes} classes): "
                                    f"HIP log-mel front end (untimed) + tiny-CNN train E={args.epochs} fixed epochs, "

@@ -45,12 +45,43 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8& p
     p2 = __builtin_bit_cast(bf16x8, w2);
 }
 
+// four consecutive-k floats -> three 8-byte pieces of 4 bf16 each (planes a0, a1, a2)
+__device__ __forceinline__ void split4(const f32x4 v, uint2& w0, uint2& w1, uint2& w2) {
+    unsigned o0[2], o1[2], o2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float x = v[2 * i], y = v[2 * i + 1];
+        const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+        o0[i] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
+        const float rx = x - __uint_as_float(ux & 0xFFFF0000u), ry = y - __uint_as_float(uy & 0xFFFF0000u);
+        const unsigned vx = __float_as_uint(rx), vy = __float_as_uint(ry);
+        o1[i] = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
+        const float sx = rx - __uint_as_float(vx & 0xFFFF0000u), sy = ry - __uint_as_float(vy & 0xFFFF0000u);
+        o2[i] = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), 0x07060302u);
+    }
+    w0 = make_uint2(o0[0], o0[1]);
+    w1 = make_uint2(o1[0], o1[1]);
+    w2 = make_uint2(o2[0], o2[1]);
+}
+
+// CMOOP_GEMM_MODE: unset/other = exact fp32 MFMA; "bf16x3" = split at the LDS store (MODE 2);
+// "bf16x3r" = split at the fragment read (MODE 1, kept for comparison)
+static int gemm_mode() {
+    static const int v = [] {
+        const char* e = std::getenv("CMOOP_GEMM_MODE");
+        if (!e) return 0;
+        const std::string m(e);
+        return m == "bf16x3" ? 2 : (m == "bf16x3r" ? 1 : 0);
+    }();
+    return v;
+}
 static bool gemm_mode_x3() {
     static const bool v = [] {
         const char* e = std::getenv("CMOOP_GEMM_MODE");
         return e && std::string(e) == "bf16x3";
     }();
-    return v;
+    (void)v;
+    return gemm_mode() != 0;
 }
 
 struct GeomDev {
@@ -135,7 +166,7 @@ static GeomDev to_dev(const ConvGeom& g) {
 // RT x CT MFMA tiles of 16x16.  Tile shape is picked per layer so that the grid
 // fills the 256 CUs (small-spatial deep layers use 64-row tiles).
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int BK, int WM, bool X3 = false>
+template <int BM, int BN, int BK, int WM, int MODE = 0>   // MODE 0 exact fp32 MFMA, 1 bf16x3 split at fragment read, 2 bf16x3 split at LDS store
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                         float* __restrict__ Y, GeomDev g, EpiDev e,
                                                         float* __restrict__ slab, int chunks_per_split) {
@@ -147,8 +178,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     constexpr int BPASS = (BN + RPP - 1) / RPP;
     constexpr int RT = BM / WM / 16, CT = BN / WN / 16;
     static_assert(RT >= 1 && CT >= 1, "tile too small for the wave layout");
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+    constexpr bool X3 = MODE == 1;
+    constexpr int LDH = 40;   // MODE 2: bf16 rows of 32 k + 8 pad = 80 B (16-B aligned fragments, conflict-free b128 reads)
+    __shared__ __attribute__((aligned(16))) float As[MODE == 2 ? 1 : 2][MODE == 2 ? 4 : BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[MODE == 2 ? 1 : 2][MODE == 2 ? 4 : BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[3][MODE == 2 ? BM * LDH : 8];
+    __shared__ __attribute__((aligned(16))) unsigned short Bh[3][MODE == 2 ? BN * LDH : 8];
 
     const int t = threadIdx.x;
     // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each
@@ -182,7 +217,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     // two register sets: the loads of chunk c+2 are issued before chunk c is computed and are
     // written to LDS only after chunk c+1's compute, so a global-load round trip has two MFMA
     // phases to land (the 64-row tiles of the deep layers have only ~1k MFMA cycles per phase)
-    f32x4 ra0[APASS], rb0[BPASS], ra1[BM <= 64 ? APASS : 1], rb1[BM <= 64 ? BPASS : 1];
+    f32x4 ra0[APASS], rb0[BPASS], ra1[(BM <= 64 && MODE != 2) ? APASS : 1], rb1[(BM <= 64 && MODE != 2) ? BPASS : 1];
     auto load_chunk = [&](int c, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
         const int kidx = c * BK + 4 * kq;
         const bool kok = kidx < g.K;
@@ -216,6 +251,33 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         }
     };
 
+    // MODE 2: split each float4 (4 consecutive k of one row) exactly into three bf16 quads and store one
+    // 8-byte piece per plane
+    auto store_split = [&](const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            int ml = lrow + p * RPP;
+            if (ml < BM) {
+                uint2 w0, w1, w2;
+                split4(ra[p], w0, w1, w2);
+                *reinterpret_cast<uint2*>(&Ah[0][ml * LDH + 4 * kq]) = w0;
+                *reinterpret_cast<uint2*>(&Ah[1][ml * LDH + 4 * kq]) = w1;
+                *reinterpret_cast<uint2*>(&Ah[2][ml * LDH + 4 * kq]) = w2;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            int nl = lrow + p * RPP;
+            if (nl < BN) {
+                uint2 w0, w1, w2;
+                split4(rb[p], w0, w1, w2);
+                *reinterpret_cast<uint2*>(&Bh[0][nl * LDH + 4 * kq]) = w0;
+                *reinterpret_cast<uint2*>(&Bh[1][nl * LDH + 4 * kq]) = w1;
+                *reinterpret_cast<uint2*>(&Bh[2][nl * LDH + 4 * kq]) = w2;
+            }
+        }
+    };
+
     const int wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
     const int wrow = (wave / WN) * (BM / WM), wcol = (wave % WN) * (BN / WN);
     f32x4 acc[RT][CT];
@@ -225,6 +287,41 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
+        if constexpr (MODE == 2) {
+            // fragments are ready-made bf16x8: lane (lr, q) reads 16 B = k 8q..8q+7 of its row from each plane
+            static_assert(MODE != 2 || BK == 32, "bf16x3 path needs 32-deep K chunks");
+            bf16x8 b0[CT], b1[CT], b2[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int o = (wcol + ct * 16 + lr) * LDH + q * 8;
+                b0[ct] = *reinterpret_cast<const bf16x8*>(&Bh[0][o]);
+                b1[ct] = *reinterpret_cast<const bf16x8*>(&Bh[1][o]);
+                b2[ct] = *reinterpret_cast<const bf16x8*>(&Bh[2][o]);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int o = (wrow + rt * 16 + lr) * LDH + q * 8;
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&Ah[0][o]);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Ah[1][o]);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&Ah[2][o]);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[ct], acc[rt][ct], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            (void)buf;
+            return;
+        }
         if constexpr (X3) {
             // one 16x16x32 bf16 k-step per 32-deep chunk; lane (lr, q) holds k = 8q..8q+7 of its row
             static_assert(!X3 || BK == 32, "bf16x3 path needs 32-deep K chunks");
@@ -282,7 +379,19 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     // split-K: blockIdx.z owns K chunks [cbeg, nchunks) and writes raw partial sums to its slab
     const int cbeg = blockIdx.z * chunks_per_split;
     const int nchunks = min((g.K + BK - 1) / BK, cbeg + chunks_per_split);
-    if constexpr (BM <= 64) {
+    if constexpr (MODE == 2) {
+        // single LDS image (three bf16 planes per operand), next chunk's global loads in flight during the MFMAs
+        // (a two-chunk-deep prefetch in two register sets was measured: it drops the kernel to one workgroup per
+        // CU and loses 25-35 %)
+        load_chunk(cbeg, ra0, rb0);
+        for (int c = cbeg; c < nchunks; ++c) {
+            store_split(ra0, rb0);
+            __syncthreads();
+            if (c + 1 < nchunks) load_chunk(c + 1, ra0, rb0);
+            compute(0);
+            __syncthreads();
+        }
+    } else if constexpr (BM <= 64) {
         // distance-2 prefetch (two register sets) for the small tiles of the deep layers
         load_chunk(cbeg, ra0, rb0);
         store_chunk(0, ra0, rb0);
@@ -410,7 +519,7 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
     }
 }
 
-template <int BM, int BN, int BK, int WM, bool X3 = false>
+template <int BM, int BN, int BK, int WM, int MODE = 0>
 static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDev& g, const EpiDev& e, hipStream_t s,
                          const GemmTiming* tm, float* slab, int splits) {
     dim3 grid(cdiv(g.M, BM), cdiv(g.Cout, BN), splits);
@@ -418,11 +527,11 @@ static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDe
     const int cps = cdiv(nchunks, splits);
     float* sl = splits > 1 ? slab : nullptr;
     if (tm && tm->start && tm->ext) {
-        hipExtLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM, X3>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, Wt, Y, g,
+        hipExtLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM, MODE>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, Wt, Y, g,
                               e, sl, cps);
     } else {
         if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));
-        hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM, X3>), grid, dim3(256), 0, s, X, Wt, Y, g, e, sl, cps);
+        hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM, MODE>), grid, dim3(256), 0, s, X, Wt, Y, g, e, sl, cps);
         if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));
     }
     CMOOP_HIP(hipGetLastError());
@@ -514,7 +623,8 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     const bool bk32_tile = x3 || (bk32 && !(bm == 128 && bn == 64 && splits == 1 && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024));
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \
     do {                                                                                      \
-        if (x3) launch_fwd_t<BM_, BN_, 32, WM_, true>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);     \
+        if (x3 && gemm_mode() == 2) launch_fwd_t<BM_, BN_, 32, WM_, 2>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);   \
+        else if (x3) launch_fwd_t<BM_, BN_, 32, WM_, 1>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);     \
         else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);   \
         else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);        \
     } while (0)

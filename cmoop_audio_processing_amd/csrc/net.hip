@@ -419,11 +419,14 @@ void Net::drain_profile() {
             const int code = ev_pool_[i].code;
             const int bm = code / 100000, bn = (code / 100) % 1000, bk = code % 100;
             const int wm = (bm == bn) ? 2 : 4;   // wave layout of each instantiation (gemm.hip)
-            static const bool x3 = [] { const char* e = std::getenv("CMOOP_GEMM_MODE"); return e && std::string(e) == "bf16x3"; }() ;
-            const bool is_x3 = x3 && bk == 32;
+            static const int x3 = [] {
+                const char* e = std::getenv("CMOOP_GEMM_MODE");
+                return !e ? 0 : (std::string(e) == "bf16x3" ? 2 : (std::string(e) == "bf16x3r" ? 1 : 0));
+            }();
+            const int mode = bk == 32 ? x3 : 0;
             const std::string name = ev_pool_[i].cls == 0
                 ? "igemm_fwd_kernel<" + std::to_string(bm) + ", " + std::to_string(bn) + ", " + std::to_string(bk) + ", " +
-                      std::to_string(wm) + (is_x3 ? ", true>" : ", false>")
+                      std::to_string(wm) + ", " + std::to_string(mode) + ">"
                 : "igemm_wgrad_kernel<" + std::to_string(code / 1000) + ", " + std::to_string(code % 1000) + ">";
             ProfileEntry& e = t.by_kernel[name];
             e.ms += ms;
