@@ -38,6 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+# opt-in modes: the bf16 MFMA runs at 16x the fp32 MFMA rate (same guide); bf16x3 spends six bf16 MFMAs per product
+PEAK_BY_MODE = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": round(16 * PEAK_FP32_MFMA_TFLOPS / 6, 1), "bf16": 16 * PEAK_FP32_MFMA_TFLOPS}
 
 
 def synth_waveforms(n, classes, seed, device, n_samples=16000, chunk=2000):
@@ -118,9 +120,10 @@ def main():
     ap.add_argument("--weak", action="store_true", help="population = pop * gpus")
     ap.add_argument("--profile-every", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm-mode", default="fp32", choices=["fp32", "bf16x3", "bf16x3r"],
-                    help="fp32 = exact fp32 MFMA (the product path). bf16x3 = EXPERIMENTAL opt-in: forward/dgrad GEMMs split every "
-                         "fp32 operand exactly into three bf16 values and use six bf16 MFMA terms (fp32-accurate, not bit-exact)")
+    ap.add_argument("--gemm-mode", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="fp32 = exact fp32 MFMA (the product path, what the reference computes in). Opt-in bf16 matrix-core modes: "
+                         "bf16x3 = every fp32 GEMM operand split exactly into three bf16 values, six bf16 MFMA terms (fp32-accurate, "
+                         "not bit-exact); bf16 = operands rounded to bf16, fp32 accumulation (BASELINE configs[4] 'bf16 train')")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --same-device rehearses N ranks on one GPU")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (single-GPU rehearsal of the N>1 path)")
     args = ap.parse_args()
@@ -132,6 +135,9 @@ def main():
         os.environ["CMOOP_PROFILE_PAIRS"] = "1"
     if args.gemm_mode != "fp32":
         os.environ["CMOOP_GEMM_MODE"] = args.gemm_mode      # read once by the library
+
+    global PEAK_FP32_MFMA_TFLOPS
+    PEAK_FP32_MFMA_TFLOPS = PEAK_BY_MODE[args.gemm_mode]   # the roofline of the arithmetic actually used
 
     import torch
     import torch.distributed as dist
@@ -277,7 +283,8 @@ def main():
             "metric": "candidate-net evals/hour (pop=40, GSC-v2)", "value": round(value, 2), "unit": "candidate-evals/hour",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 2),
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-            "dtype": "f32" if args.gemm_mode == "fp32" else f"f32 operands as 3 x bf16 ({args.gemm_mode}, EXPERIMENTAL, fwd/dgrad GEMMs only)",
+            "dtype": {"fp32": "f32", "bf16x3": "f32 operands as 3 x bf16 (opt-in bf16x3 mode, fp32-accurate)",
+                      "bf16": "bf16 operands, f32 accumulate (opt-in bf16-train mode)"}[args.gemm_mode],
             "data": "synthetic",
             "config": {"workload": f"pop={n_pop} gen=1 fitness eval (topology {args.variant}, {args.classes} classes): "
                                    f"HIP log-mel front end (untimed) + tiny-CNN train E={args.epochs} fixed epochs, "

@@ -29,7 +29,7 @@ class Config(C.Structure):
     """cmoop_config (include/cmoop.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "variant", "classes", "epochs", "batch", "patience", "early_stop", "restore_best", "acc_readout",
-        "fpr_variant", "shuffle", "eval_batch", "n_slots", "profile_every", "reserved")] + \
+        "fpr_variant", "shuffle", "eval_batch", "n_slots", "profile_every", "gemm_mode")] + \
         [(n, C.c_double) for n in ("lr", "beta1", "beta2", "adam_eps", "bn_eps", "bn_momentum", "dropout")]
 
 

@@ -42,12 +42,14 @@ static NetConfig to_cfg(const cmoop_config* c) {
     n.early_stop = c->early_stop; n.restore_best = c->restore_best; n.acc_readout = c->acc_readout;
     n.fpr_variant = c->fpr_variant; n.shuffle = c->shuffle; n.eval_batch = c->eval_batch; n.n_slots = c->n_slots;
     n.profile_every = c->profile_every;
+    n.gemm_mode = c->gemm_mode == CMOOP_GEMM_DEFAULT ? gemm_mode_default() : c->gemm_mode;
     n.lr = c->lr; n.beta1 = c->beta1; n.beta2 = c->beta2; n.adam_eps = c->adam_eps; n.bn_eps = c->bn_eps;
     n.bn_momentum = c->bn_momentum; n.dropout = c->dropout;
     CMOOP_REQUIRE(n.variant == 0 || n.variant == 1, "variant must be CMOOP_VARIANT_A or _B");
     CMOOP_REQUIRE(n.fpr_variant >= 0 && n.fpr_variant <= 2, "bad fpr_variant");
     CMOOP_REQUIRE(n.epochs >= 0 && n.patience >= 0 && n.batch >= 1 && n.eval_batch >= 1, "bad epochs/patience/batch");
     CMOOP_REQUIRE(n.dropout >= 0.0 && n.dropout < 1.0, "dropout must be in [0,1)");
+    CMOOP_REQUIRE(n.gemm_mode == GEMM_FP32 || n.gemm_mode == GEMM_BF16X3 || n.gemm_mode == GEMM_BF16, "bad gemm_mode");
     return n;
 }
 

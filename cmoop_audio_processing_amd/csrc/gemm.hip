@@ -20,68 +20,53 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
-// OPT-IN "bf16x3" mode (CMOOP_GEMM_MODE=bf16x3): every fp32 operand is split EXACTLY into three bf16
-// values by truncation (a = a0 + a1 + a2, 8+8+8 mantissa bits) and a product is evaluated as the six
-// bf16 MFMA terms a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0 accumulated in fp32 (dropped terms < 2^-24
-// relative).  v_mfma_f32_16x16x32_bf16 runs at 16x the fp32 MFMA rate, so six of them still cost 2.7x less
-// pipe time than the eight exact-fp32 MFMAs they replace.  NOT the default: results are fp32-accurate
-// (same parity tolerances) but not the bit-exact fmaf chain of the fp32 MFMA.
+// OPT-IN bf16 matrix-core modes (cfg.gemm_mode / CMOOP_GEMM_MODE; the default is the exact fp32 MFMA):
+//  * GEMM_BF16X3 ("bf16x3"): every fp32 operand is split EXACTLY into three bf16 values by truncation
+//    (a = a0 + a1 + a2, 8+8+8 mantissa bits) and a product is evaluated as the six bf16 MFMA terms
+//    a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0 accumulated in fp32 (dropped terms < 2^-24 relative).
+//    v_mfma_f32_16x16x32_bf16 runs at 16x the fp32 MFMA rate, so six of them still cost 2.7x less pipe time
+//    than the eight exact-fp32 MFMAs they replace.  fp32-accurate (same parity tolerances), not bit-exact.
+//  * GEMM_BF16 ("bf16"): operands rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32), one MFMA term,
+//    fp32 accumulation -- "bf16 train" (BASELINE configs[4]); the oracle restates the same rounding.
+// Both split/round once, at the global->LDS store, into bf16 planes laid out so that an MFMA fragment
+// (8 consecutive k of one row) is a single conflict-free ds_read_b128.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
-    u32x4 w0, w1, w2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float x = i < 2 ? lo[2 * i] : hi[2 * i - 4], y = i < 2 ? lo[2 * i + 1] : hi[2 * i - 3];
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (x, y) -> packed bf16 pair per plane, x in the low half.  NP = 3: exact truncation split; NP = 1: RNE rounding
+template <int NP>
+__device__ __forceinline__ void split_pair(const float x, const float y, unsigned (&w)[NP]) {
+    if constexpr (NP == 1) {
+        w[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x, y}, bf16x2));
+    } else {
         const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
-        w0[i] = (uy & 0xFFFF0000u) | (ux >> 16);
+        w[0] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
         const float rx = x - __uint_as_float(ux & 0xFFFF0000u), ry = y - __uint_as_float(uy & 0xFFFF0000u);
         const unsigned vx = __float_as_uint(rx), vy = __float_as_uint(ry);
-        w1[i] = (vy & 0xFFFF0000u) | (vx >> 16);
+        w[1] = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
         const float sx = rx - __uint_as_float(vx & 0xFFFF0000u), sy = ry - __uint_as_float(vy & 0xFFFF0000u);
-        w2[i] = (__float_as_uint(sy) & 0xFFFF0000u) | (__float_as_uint(sx) >> 16);
+        w[2] = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), 0x07060302u);
     }
-    p0 = __builtin_bit_cast(bf16x8, w0);
-    p1 = __builtin_bit_cast(bf16x8, w1);
-    p2 = __builtin_bit_cast(bf16x8, w2);
 }
 
-// four consecutive-k floats -> three 8-byte pieces of 4 bf16 each (planes a0, a1, a2)
-__device__ __forceinline__ void split4(const f32x4 v, uint2& w0, uint2& w1, uint2& w2) {
-    unsigned o0[2], o1[2], o2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float x = v[2 * i], y = v[2 * i + 1];
-        const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
-        o0[i] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
-        const float rx = x - __uint_as_float(ux & 0xFFFF0000u), ry = y - __uint_as_float(uy & 0xFFFF0000u);
-        const unsigned vx = __float_as_uint(rx), vy = __float_as_uint(ry);
-        o1[i] = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
-        const float sx = rx - __uint_as_float(vx & 0xFFFF0000u), sy = ry - __uint_as_float(vy & 0xFFFF0000u);
-        o2[i] = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), 0x07060302u);
-    }
-    w0 = make_uint2(o0[0], o0[1]);
-    w1 = make_uint2(o1[0], o1[1]);
-    w2 = make_uint2(o2[0], o2[1]);
-}
+// the six product terms of one bf16x3 tile update, small terms first: (a2b0, a1b1, a0b2, a1b0, a0b1, a0b0);
+// single-plane bf16 uses only the last
+__device__ constexpr int X3_TA[6] = {2, 1, 0, 1, 0, 0};
+__device__ constexpr int X3_TB[6] = {0, 1, 2, 0, 1, 0};
 
-// CMOOP_GEMM_MODE: unset/other = exact fp32 MFMA; "bf16x3" = split at the LDS store (MODE 2);
-// "bf16x3r" = split at the fragment read (MODE 1, kept for comparison)
-static int gemm_mode() {
+int gemm_mode_default() {
     static const int v = [] {
         const char* e = std::getenv("CMOOP_GEMM_MODE");
-        if (!e) return 0;
+        if (!e) return (int)GEMM_FP32;
         const std::string m(e);
-        return m == "bf16x3" ? 2 : (m == "bf16x3r" ? 1 : 0);
+        return m == "bf16x3" ? (int)GEMM_BF16X3 : (m == "bf16" ? (int)GEMM_BF16 : (int)GEMM_FP32);
     }();
     return v;
 }
-static bool gemm_mode_x3() {
-    static const bool v = [] {
-        const char* e = std::getenv("CMOOP_GEMM_MODE");
-        return e && std::string(e) == "bf16x3";
-    }();
-    (void)v;
-    return gemm_mode() != 0;
+static int resolve_mode(int mode) {
+    const int m = mode >= 0 ? mode : gemm_mode_default();
+    return (m == GEMM_BF16X3 || m == GEMM_BF16) ? m : GEMM_FP32;
 }
 
 struct GeomDev {
@@ -166,10 +151,13 @@ static GeomDev to_dev(const ConvGeom& g) {
 // RT x CT MFMA tiles of 16x16.  Tile shape is picked per layer so that the grid
 // fills the 256 CUs (small-spatial deep layers use 64-row tiles).
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int BK, int WM, int MODE = 0>   // MODE 0 exact fp32 MFMA, 1 bf16x3 split at fragment read, 2 bf16x3 split at LDS store
+template <int BM, int BN, int BK, int WM, int MODE = 0>   // MODE: GEMM_FP32 exact fp32 MFMA, GEMM_BF16X3 / GEMM_BF16 bf16 planes
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                         float* __restrict__ Y, GeomDev g, EpiDev e,
                                                         float* __restrict__ slab, int chunks_per_split) {
+    static_assert(MODE == GEMM_FP32 || MODE == GEMM_BF16X3 || MODE == GEMM_BF16, "unknown GEMM mode");
+    constexpr bool PLANES = MODE != GEMM_FP32;
+    constexpr int NP = MODE == GEMM_BF16X3 ? 3 : 1;
     constexpr int WN = 4 / WM;
     constexpr int LDK = BK + 4;
     constexpr int TPR = BK / 4;
@@ -178,12 +166,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     constexpr int BPASS = (BN + RPP - 1) / RPP;
     constexpr int RT = BM / WM / 16, CT = BN / WN / 16;
     static_assert(RT >= 1 && CT >= 1, "tile too small for the wave layout");
-    constexpr bool X3 = MODE == 1;
-    constexpr int LDH = 40;   // MODE 2: bf16 rows of 32 k + 8 pad = 80 B (16-B aligned fragments, conflict-free b128 reads)
-    __shared__ __attribute__((aligned(16))) float As[MODE == 2 ? 1 : 2][MODE == 2 ? 4 : BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[MODE == 2 ? 1 : 2][MODE == 2 ? 4 : BN * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Ah[3][MODE == 2 ? BM * LDH : 8];
-    __shared__ __attribute__((aligned(16))) unsigned short Bh[3][MODE == 2 ? BN * LDH : 8];
+    static_assert(!PLANES || BK == 32, "bf16 planes need 32-deep K chunks");
+    constexpr int LDH = 40;   // bf16 planes: rows of 32 k + 8 pad = 80 B (16-B aligned fragments, conflict-free b128 reads)
+    __shared__ __attribute__((aligned(16))) float As[PLANES ? 1 : 2][PLANES ? 4 : BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[PLANES ? 1 : 2][PLANES ? 4 : BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[NP][PLANES ? BM * LDH : 8];
+    __shared__ __attribute__((aligned(16))) unsigned short Bh[NP][PLANES ? BN * LDH : 8];
 
     const int t = threadIdx.x;
     // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each
@@ -217,7 +205,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     // two register sets: the loads of chunk c+2 are issued before chunk c is computed and are
     // written to LDS only after chunk c+1's compute, so a global-load round trip has two MFMA
     // phases to land (the 64-row tiles of the deep layers have only ~1k MFMA cycles per phase)
-    f32x4 ra0[APASS], rb0[BPASS], ra1[(BM <= 64 && MODE != 2) ? APASS : 1], rb1[(BM <= 64 && MODE != 2) ? BPASS : 1];
+    f32x4 ra0[APASS], rb0[BPASS], ra1[(BM <= 64 && !PLANES) ? APASS : 1], rb1[(BM <= 64 && !PLANES) ? BPASS : 1];
     auto load_chunk = [&](int c, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
         const int kidx = c * BK + 4 * kq;
         const bool kok = kidx < g.K;
@@ -251,29 +239,28 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         }
     };
 
-    // MODE 2: split each float4 (4 consecutive k of one row) exactly into three bf16 quads and store one
-    // 8-byte piece per plane
+    // bf16 planes: split (or round) each float4 -- 4 consecutive k of one row -- and store one 8-byte piece per plane
     auto store_split = [&](const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
             int ml = lrow + p * RPP;
             if (ml < BM) {
-                uint2 w0, w1, w2;
-                split4(ra[p], w0, w1, w2);
-                *reinterpret_cast<uint2*>(&Ah[0][ml * LDH + 4 * kq]) = w0;
-                *reinterpret_cast<uint2*>(&Ah[1][ml * LDH + 4 * kq]) = w1;
-                *reinterpret_cast<uint2*>(&Ah[2][ml * LDH + 4 * kq]) = w2;
+                unsigned lo[NP], hi[NP];
+                split_pair<NP>(ra[p][0], ra[p][1], lo);
+                split_pair<NP>(ra[p][2], ra[p][3], hi);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(&Ah[pl][ml * LDH + 4 * kq]) = make_uint2(lo[pl], hi[pl]);
             }
         }
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             int nl = lrow + p * RPP;
             if (nl < BN) {
-                uint2 w0, w1, w2;
-                split4(rb[p], w0, w1, w2);
-                *reinterpret_cast<uint2*>(&Bh[0][nl * LDH + 4 * kq]) = w0;
-                *reinterpret_cast<uint2*>(&Bh[1][nl * LDH + 4 * kq]) = w1;
-                *reinterpret_cast<uint2*>(&Bh[2][nl * LDH + 4 * kq]) = w2;
+                unsigned lo[NP], hi[NP];
+                split_pair<NP>(rb[p][0], rb[p][1], lo);
+                split_pair<NP>(rb[p][2], rb[p][3], hi);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(&Bh[pl][nl * LDH + 4 * kq]) = make_uint2(lo[pl], hi[pl]);
             }
         }
     };
@@ -287,70 +274,30 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
-        if constexpr (MODE == 2) {
+        if constexpr (PLANES) {
             // fragments are ready-made bf16x8: lane (lr, q) reads 16 B = k 8q..8q+7 of its row from each plane
-            static_assert(MODE != 2 || BK == 32, "bf16x3 path needs 32-deep K chunks");
-            bf16x8 b0[CT], b1[CT], b2[CT];
+            bf16x8 b[CT][NP];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int o = (wcol + ct * 16 + lr) * LDH + q * 8;
-                b0[ct] = *reinterpret_cast<const bf16x8*>(&Bh[0][o]);
-                b1[ct] = *reinterpret_cast<const bf16x8*>(&Bh[1][o]);
-                b2[ct] = *reinterpret_cast<const bf16x8*>(&Bh[2][o]);
-            }
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    b[ct][pl] = *reinterpret_cast<const bf16x8*>(&Bh[pl][(wcol + ct * 16 + lr) * LDH + q * 8]);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const int o = (wrow + rt * 16 + lr) * LDH + q * 8;
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&Ah[0][o]);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Ah[1][o]);
-                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&Ah[2][o]);
+                bf16x8 a[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    a[pl] = *reinterpret_cast<const bf16x8*>(&Ah[pl][(wrow + rt * 16 + lr) * LDH + q * 8]);
                 __builtin_amdgcn_s_setprio(1);
+                // term-major order: consecutive MFMAs hit different accumulators (no dependent back-to-back issue)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0[ct], acc[rt][ct], 0, 0, 0);
+                for (int term = (NP == 3 ? 0 : 5); term < 6; ++term)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[ct], acc[rt][ct], 0, 0, 0);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2[ct], acc[rt][ct], 0, 0, 0);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0[ct], acc[rt][ct], 0, 0, 0);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1[ct], acc[rt][ct], 0, 0, 0);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[ct], acc[rt][ct], 0, 0, 0);
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[X3_TA[term] % NP], b[ct][X3_TB[term] % NP], acc[rt][ct], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
             }
             (void)buf;
-            return;
-        }
-        if constexpr (X3) {
-            // one 16x16x32 bf16 k-step per 32-deep chunk; lane (lr, q) holds k = 8q..8q+7 of its row
-            static_assert(!X3 || BK == 32, "bf16x3 path needs 32-deep K chunks");
-            bf16x8 a0[RT], a1[RT], a2[RT], b0[CT], b1[CT], b2[CT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const float* pa = &As[buf][(wrow + rt * 16 + lr) * LDK + q * 8];
-                split8(*reinterpret_cast<const f32x4*>(pa), *reinterpret_cast<const f32x4*>(pa + 4), a0[rt], a1[rt], a2[rt]);
-            }
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const float* pb = &Bs[buf][(wcol + ct * 16 + lr) * LDK + q * 8];
-                split8(*reinterpret_cast<const f32x4*>(pb), *reinterpret_cast<const f32x4*>(pb + 4), b0[ct], b1[ct], b2[ct]);
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    f32x4 c = acc[rt][ct];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[rt], b0[ct], c, 0, 0, 0);   // small terms first
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[rt], b1[ct], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b2[ct], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[rt], b0[ct], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b1[ct], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b0[ct], c, 0, 0, 0);
-                    acc[rt][ct] = c;
-                }
-            __builtin_amdgcn_s_setprio(0);
             return;
         }
 #pragma unroll
@@ -379,8 +326,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     // split-K: blockIdx.z owns K chunks [cbeg, nchunks) and writes raw partial sums to its slab
     const int cbeg = blockIdx.z * chunks_per_split;
     const int nchunks = min((g.K + BK - 1) / BK, cbeg + chunks_per_split);
-    if constexpr (MODE == 2) {
-        // single LDS image (three bf16 planes per operand), next chunk's global loads in flight during the MFMAs
+    if constexpr (PLANES) {
+        // single LDS image (bf16 planes per operand), next chunk's global loads in flight during the MFMAs
         // (a two-chunk-deep prefetch in two register sets was measured: it drops the kernel to one workgroup per
         // CU and loses 25-35 %)
         load_chunk(cbeg, ra0, rb0);
@@ -614,17 +561,20 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     e.dropout = ep.dropout; e.drop_prefix = ep.drop_prefix; e.drop_thr = ep.drop_thr; e.drop_scale = ep.drop_scale;
     if (e.out_stride > 1)
         CMOOP_REQUIRE((int64_t)g.B * e.OHf * e.OWf * g.Cout < (1ll << 31), "scattered output too large");
-    const bool bk32 = (g.Cin % 32 == 0);
+    const int mode = resolve_mode(ep.mode);
+    // bf16 planes always use 32-deep chunks (a chunk may span two taps of a 16-channel layer; the per-thread tap decode
+    // and the k < K guard handle that)
+    const bool bk32 = mode != GEMM_FP32 || (g.Cin % 32 == 0);
     int bm, bn, splits;
     pick_tile(g.M, g.Cout, g.K, bk32 ? 32 : 16, splitk_ws ? splitk_ws_floats : 0, &bm, &bn, &splits);
     // many-wave grids of 128x64 tiles run 3-4 % faster with 16-deep K chunks (half the LDS, 4-5 workgroups
     // per CU instead of 2); single-wave grids prefer the 32-deep chunk (half the barriers)
-    const bool x3 = bk32 && gemm_mode_x3();
-    const bool bk32_tile = x3 || (bk32 && !(bm == 128 && bn == 64 && splits == 1 && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024));
+    const bool bk32_tile = mode != GEMM_FP32 ||
+                           (bk32 && !(bm == 128 && bn == 64 && splits == 1 && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024));
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \
     do {                                                                                      \
-        if (x3 && gemm_mode() == 2) launch_fwd_t<BM_, BN_, 32, WM_, 2>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);   \
-        else if (x3) launch_fwd_t<BM_, BN_, 32, WM_, 1>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);     \
+        if (mode == GEMM_BF16X3) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16X3>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);   \
+        else if (mode == GEMM_BF16) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);  \
         else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);   \
         else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);        \
     } while (0)
@@ -639,7 +589,7 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
         else CMOOP_FWD(64, 16, 4);
     }
 #undef CMOOP_FWD
-    return bm * 100000 + bn * 100 + (bk32_tile ? 32 : 16);
+    return mode * 100000000 + bm * 100000 + bn * 100 + (bk32_tile ? 32 : 16);
 }
 
 // ---------------------------------------------------------------------------
@@ -788,6 +738,152 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
         }
 }
 
+// ---------------------------------------------------------------------------
+// weight-gradient kernel on the bf16 matrix core (GEMM_BF16X3: NP = 3 exact-split planes; GEMM_BF16: NP = 1).
+// Same grid / slices / partial layout as igemm_wgrad_kernel.  The reduction index of the MFMA is the pixel row m,
+// but both operands arrive m-major (dY[m][co], im2col(X)[m][k]), so the transposition happens on the way into
+// LDS: a loader thread owns 8 consecutive rows x 4 columns, splits/rounds them, packs row PAIRS into 32-bit
+// words and writes, per plane and column, ONE 16-byte piece = 8 consecutive m of that column -- exactly an MFMA
+// fragment, read back with a single ds_read_b128.  Line pitch 20 words (16 + 4 pad) keeps both the b128
+// stores (lanes ordered row-group fastest) and the fragment reads conflict-free.
+// Threads [0, BKI) load X, [BKI, BKI + BCO) load dY (wave-uniform roles for the 64/128 tiles).
+// ---------------------------------------------------------------------------
+template <int BCO, int BKI, int NP>
+__global__ __launch_bounds__(256) void igemm_wgrad_bf16_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                               float* __restrict__ P, GeomDev g, int rows_per_slice,
+                                                               float* __restrict__ Pbias, size_t slab_stride) {
+    constexpr int MC = 32, PITCH = 20;
+    constexpr int CT = BCO / 16, KT = BKI / 16;
+    constexpr int WC = CT >= 8 ? 2 : (CT >= 4 ? 4 : CT);
+    constexpr int WK = 4 / WC;
+    constexpr int CPW = CT / WC, KPW = KT / WK;
+    static_assert(BKI + BCO <= 256, "loader roles need BKI + BCO threads");
+    __shared__ __attribute__((aligned(16))) unsigned Xh[NP][BKI * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned Yh[NP][BCO * PITCH];
+
+    const int t = threadIdx.x;
+    const int k0 = blockIdx.x * BKI, co0 = blockIdx.y * BCO;
+    const int mbeg = blockIdx.z * rows_per_slice;
+    const int mend = min(g.M, mbeg + rows_per_slice);
+
+    const bool isX = t < BKI, isY = !isX && t < BKI + BCO;
+    const int tl = isX ? t : t - BKI;
+    const int rg = tl & 3, cq = tl >> 2;          // row group (rows 8rg..8rg+7 of the chunk), column quad
+    // X role: fixed k index for the block's life
+    const int kidx = k0 + 4 * cq;
+    const bool kok = isX && kidx < g.K;
+    const int tap = kidx >> g.cshift, ci = kidx & (g.Cin - 1);
+    const int kh = (tap * g.rcp_kw) >> 16, kw = tap - kh * g.KW;
+    const bool cok = isY && (co0 + 4 * cq) < g.Cout;   // launcher guarantees Cout % 4 == 0
+
+    f32x4 r[8];
+    auto load_chunk = [&](int mc) {
+        if (isX) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = mc + 8 * rg + i;
+                const int mm = m < mend ? m : 0;
+                const int b = fastdiv(mm, g.ohw_magic, g.ohw_shift), rr = mm - b * g.OHW;
+                const int oh = fastdiv(rr, g.ow_magic, g.ow_shift), ow = rr - oh * g.OW;
+                const int ih = oh * g.stride - g.pad_t + kh, iw = ow * g.stride - g.pad_l + kw;
+                const bool ok = kok && m < mend && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+                const float* src = ok ? X + (((size_t)((b * g.H + ih) * g.W + iw)) << g.cshift) + ci : g.zeros;
+                r[i] = *reinterpret_cast<const f32x4*>(src);
+            }
+        } else if (isY) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = mc + 8 * rg + i;
+                const float* src = (cok && m < mend) ? dY + (size_t)m * g.Cout + co0 + 4 * cq : g.zeros;
+                r[i] = *reinterpret_cast<const f32x4*>(src);
+            }
+        }
+    };
+    auto store_split = [&]() {
+        if (!(isX || isY)) return;
+        unsigned* base = isX ? &Xh[0][0] : &Yh[0][0];
+        const int plane_words = isX ? BKI * PITCH : BCO * PITCH;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned w[4][NP];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) split_pair<NP>(r[2 * u][j], r[2 * u + 1][j], w[u]);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                *reinterpret_cast<uint4*>(base + pl * plane_words + (4 * cq + j) * PITCH + 4 * rg) =
+                    make_uint4(w[0][pl], w[1][pl], w[2][pl], w[3][pl]);
+        }
+    };
+
+    const int wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
+    const int wave_c = wave % WC, wave_k = wave / WC;
+    f32x4 acc[CPW][KPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // bias gradient (exact fp32 column sums of dY) rides along in the blocks of the first K tile
+    const bool do_bias = Pbias != nullptr && blockIdx.x == 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const int nchunks = (mend > mbeg) ? (mend - mbeg + MC - 1) / MC : 0;
+    if (nchunks > 0) load_chunk(mbeg);
+    for (int c = 0; c < nchunks; ++c) {
+        store_split();
+        if (do_bias && isY) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bsum += r[i];     // rows past mend were loaded as zeros
+        }
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(mbeg + (c + 1) * MC);
+        bf16x8 b[KPW][NP];
+#pragma unroll
+        for (int kt = 0; kt < KPW; ++kt)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                b[kt][pl] = *reinterpret_cast<const bf16x8*>(&Xh[pl][((wave_k * KPW + kt) * 16 + lr) * PITCH + 4 * q]);
+#pragma unroll
+        for (int c2 = 0; c2 < CPW; ++c2) {
+            bf16x8 a[NP];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                a[pl] = *reinterpret_cast<const bf16x8*>(&Yh[pl][((wave_c * CPW + c2) * 16 + lr) * PITCH + 4 * q]);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int term = (NP == 3 ? 0 : 5); term < 6; ++term)
+#pragma unroll
+                for (int kt = 0; kt < KPW; ++kt)
+                    acc[c2][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[X3_TA[term] % NP], b[kt][X3_TB[term] % NP], acc[c2][kt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+    }
+
+    if (do_bias) {   // fixed-order reduction over the 4 row groups that share a column quad
+        float* red = reinterpret_cast<float*>(&Xh[0][0]);   // >= 4*BCO floats, free after the loop's last barrier
+        if (isY) *reinterpret_cast<f32x4*>(&red[4 * tl]) = bsum;
+        __syncthreads();
+        if (t < BCO && co0 + t < g.Cout) {
+            const int q4 = t >> 2, j = t & 3;
+            float sacc = 0.f;
+            for (int rr = 0; rr < 4; ++rr) sacc += red[4 * (4 * q4 + rr) + j];
+            Pbias[(size_t)blockIdx.z * slab_stride + co0 + t] = sacc;
+        }
+    }
+    float* Pout = P + (size_t)blockIdx.z * slab_stride;
+#pragma unroll
+    for (int c2 = 0; c2 < CPW; ++c2)
+#pragma unroll
+        for (int kt = 0; kt < KPW; ++kt) {
+            const int kcol = k0 + (wave_k * KPW + kt) * 16 + lr;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int co = co0 + (wave_c * CPW + c2) * 16 + q * 4 + rr;
+                if (co < g.Cout && kcol < g.K) Pout[(size_t)co * g.K + kcol] = acc[c2][kt][rr];
+            }
+        }
+}
+
 // 128-wide K tiles double the MFMA work per barrier but halve the number of tiles: use them only
 // when the grid still covers the chip with the row slices available (M / 256)
 static inline int wgrad_bco(int N) { return N <= 16 ? 16 : (N <= 32 ? 32 : (N <= 64 ? 64 : 128)); }
@@ -822,7 +918,7 @@ int wgrad_slices(const ConvGeom& g) {
 }
 
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s,
-                       const GemmTiming* tm, float* Pbias, size_t slab_stride) {
+                       const GemmTiming* tm, float* Pbias, size_t slab_stride, int mode_req) {
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
     const size_t stride = slab_stride ? slab_stride : (size_t)g.Cout * g.K;
@@ -831,16 +927,28 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     const int N = g.Cout;
     const int bco = wgrad_bco(N);
     const int bki = wgrad_bki(g.M, g.Cout, g.K);
+    // the bf16 loaders read dY as aligned float4: the classifier layer (10 / 11 / 35 columns) stays on the fp32 kernel
+    int mode = (N % 4 == 0) ? resolve_mode(mode_req) : (int)GEMM_FP32;
+    // bf16x3 pays the split VALU work per loaded element: with fewer than 128 output channels per block there are too
+    // few MFMAs per element to hide it (measured 58 vs 73 TFLOP/s on 64->64 k5) -- the exact kernel is the better
+    // fp32-accurate choice there.  (GEMM_BF16 must round everywhere to stay consistent with its definition.)
+    if (mode == GEMM_BF16X3 && bco < 128) mode = GEMM_FP32;
     dim3 grid(cdiv(g.K, bki), cdiv(N, bco), S);
-#define CMOOP_WG2(BCO_, BKI_)                                                                                   \
+#define CMOOP_WGK(KERNEL)                                                                                       \
     do {                                                                                                       \
         if (tm && tm->start && tm->ext) {                                                                      \
-            hipExtLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps, Pbias, stride); \
+            hipExtLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps, Pbias, stride); \
         } else {                                                                                               \
             if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));                                      \
-            hipLaunchKernelGGL((igemm_wgrad_kernel<BCO_, BKI_>), grid, dim3(256), 0, s, X, dY, P, g, rps, Pbias, stride); \
+            hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, X, dY, P, g, rps, Pbias, stride);                 \
             if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));                                       \
         }                                                                                                      \
+    } while (0)
+#define CMOOP_WG2(BCO_, BKI_)                                                          \
+    do {                                                                               \
+        if (mode == GEMM_BF16X3) CMOOP_WGK((igemm_wgrad_bf16_kernel<BCO_, BKI_, 3>));  \
+        else if (mode == GEMM_BF16) CMOOP_WGK((igemm_wgrad_bf16_kernel<BCO_, BKI_, 1>)); \
+        else CMOOP_WGK((igemm_wgrad_kernel<BCO_, BKI_>));                              \
     } while (0)
 #define CMOOP_WG(BCO_)                    \
     do {                                  \
@@ -853,8 +961,9 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     else CMOOP_WG(128);
 #undef CMOOP_WG
 #undef CMOOP_WG2
+#undef CMOOP_WGK
     CMOOP_HIP(hipGetLastError());
-    return bco * 1000 + bki;
+    return mode * 1000000 + bco * 1000 + bki;
 }
 
 // out[i] = sum_s P[s][i], fixed summation order.  Vector form: each thread owns one float4 column group,

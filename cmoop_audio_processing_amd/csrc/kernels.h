@@ -20,7 +20,13 @@ struct ConvGeom {
     int K() const { return KH * KW * Cin; }
 };
 
+// Arithmetic of the MFMA GEMM kernels.  GEMM_FP32 (exact v_mfma_f32_16x16x4_f32) is the product default;
+// the bf16 matrix-core modes are opt-in (cmoop_config.gemm_mode or CMOOP_GEMM_MODE=bf16x3|bf16), see gemm.hip.
+enum GemmMode { GEMM_DEFAULT = -1, GEMM_FP32 = 0, GEMM_BF16X3 = 2, GEMM_BF16 = 3 };
+int gemm_mode_default();   // CMOOP_GEMM_MODE, else GEMM_FP32
+
 struct GemmEpilogue {
+    int mode = GEMM_DEFAULT;       // GemmMode of this launch (GEMM_DEFAULT: gemm_mode_default())
     const float* bias = nullptr;   // + bias[col]
     int relu = 0;                  // max(v, 0)
     const float* mask = nullptr;   // v = mask[out] > 0 ? v * mask_scale : 0   (ReLU/dropout backward)
@@ -41,7 +47,7 @@ struct GemmTiming {
     hipEvent_t start = nullptr, stop = nullptr;
     bool ext = true;
 };
-// returns the instantiation code BM*100000 + BN*100 + BK of the kernel that was launched
+// returns the instantiation code mode*1e8 + BM*100000 + BN*100 + BK of the kernel that was launched
 // splitk_ws (optional, >= igemm_splitk_workspace(g) floats): lets under-filled grids split the K axis
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& g,
                      const GemmEpilogue& e, hipStream_t s, const GemmTiming* tm = nullptr,
@@ -50,12 +56,13 @@ size_t igemm_splitk_workspace(const ConvGeom& g);
 
 // dWt[n][k] = sum_m dY[m][n] * im2col(X)[m][k], split over S row-slices into P[S][N][K].
 int wgrad_slices(const ConvGeom& g);
-// returns the instantiation code BCO of the kernel that was launched
+// returns the instantiation code mode*1e6 + BCO*1000 + BKI of the kernel that was launched
 // Pbias (optional): [S][N] per-slice column sums of dY (the bias gradient), fused into the first K tile's blocks
 // slab_stride: floats between consecutive slices of P and of Pbias (0 = N*K, bias slabs packed [S][N]);
 // the trainer lays slices out as [S][N*K + N] so one reduction yields kernel and bias gradients.
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& g, int S, hipStream_t s,
-                       const GemmTiming* tm = nullptr, float* Pbias = nullptr, size_t slab_stride = 0);
+                       const GemmTiming* tm = nullptr, float* Pbias = nullptr, size_t slab_stride = 0,
+                       int mode = GEMM_DEFAULT);
 // out[i] = sum_s P[s][i]  (fixed order -> deterministic)
 void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s, int64_t stride = 0);
 // Wd[ci][KH-1-kh][KW-1-kw][co] = W[co][kh][kw][ci]   (operand of the dgrad implicit GEMM)

@@ -16,6 +16,7 @@ struct NetConfig {
     int variant = 0, classes = 10, epochs = 300, batch = 64, patience = 5;
     int early_stop = 1, restore_best = 0, acc_readout = 0, fpr_variant = 0, shuffle = 1;
     int eval_batch = 256, n_slots = 8, profile_every = 0;
+    int gemm_mode = GEMM_FP32;   // resolved GemmMode of the MFMA layers (never GEMM_DEFAULT here)
     double lr = 1e-3, beta1 = 0.9, beta2 = 0.999, adam_eps = 1e-7, bn_eps = 1e-3, bn_momentum = 0.99, dropout = 0.3;
 };
 
@@ -45,10 +46,10 @@ struct GemmHook {   // brackets every MFMA GEMM launch (HIP-event sampling)
     virtual ~GemmHook() {}
 };
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
-                           float* red_ws, hipStream_t s, GemmHook* hook);
+                           float* red_ws, hipStream_t s, GemmHook* hook, int mode = GEMM_DEFAULT);
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
                         float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws = nullptr,
-                        size_t sk_floats = 0);
+                        size_t sk_floats = 0, int mode = GEMM_DEFAULT);
 
 struct Act {
     float* data = nullptr;
@@ -67,6 +68,7 @@ struct Op {
     int KS = 1, stride = 1, Cin = 0, Cout = 0;
     int relu = 0, need_dgrad = 1, in_is_relu = 0, dgrad_accumulate = 0, dropout_layer = -1;
     float in_mask_scale = 1.f;
+    int gemm_mode = GEMM_FP32;   // arithmetic of this layer's three GEMMs
     int64_t w_off = 0, b_off = 0;
     int tensor_index = 0;   // canonical index of the kernel tensor (RNG init stream)
     // bn

@@ -125,6 +125,7 @@ void Net::build_plan() {
         op.KS = KS; op.stride = stride; op.Cin = ia.C; op.Cout = Cout; op.relu = relu;
         op.in_is_relu = in_is_relu; op.in_mask_scale = mask_scale; op.dgrad_accumulate = accumulate;
         op.w_off = off; op.tensor_index = tindex;
+        op.gemm_mode = cfg_.gemm_mode;
         off += (int64_t)Cout * KS * KS * ia.C;
         op.b_off = off; off += Cout;
         tindex += 2;
@@ -203,6 +204,7 @@ void Net::build_plan() {
         if (dr) ops_.back().dropout_layer = i;
     }
     x = add_conv(OP_DENSE, x, cfg_.classes, 1, 1, 0, 1, dr ? keep_scale : 1.f, 0);
+    ops_.back().gemm_mode = GEMM_FP32;   // the classifier layer stays fp32 in every mode (as does the C_in = 1 first conv)
     logits_ = x;
     n_params_ = off;
     CMOOP_REQUIRE(n_params_ == param_count(gene_, cfg_.variant, cfg_.classes), "plan / closed-form parameter count mismatch");
@@ -350,7 +352,7 @@ void Net::end(int code) {
 
 // dW[N][K] and db[N] of a conv / dense layer: MFMA split over row slices, then a fixed-order slice sum
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
-                           float* red_ws, hipStream_t s, GemmHook* hook) {
+                           float* red_ws, hipStream_t s, GemmHook* hook, int mode) {
     const int M = g.M(), N = g.Cout, K = g.K();
     const int S = wgrad_slices(g);
     // slices are laid out [S][N*K + N] (kernel partials then bias partials): when dB directly follows dW
@@ -360,7 +362,7 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
     float* Pk = in_place ? dW : wgrad_ws;
     float* Pbias = in_place ? dB : wgrad_ws + NK;
     const GemmTiming* tm = hook ? hook->begin(1, 2.0 * M * (double)N * K) : nullptr;
-    const int code = launch_igemm_wgrad(X, dY, Pk, g, S, s, tm, Pbias, in_place ? NK : stride);
+    const int code = launch_igemm_wgrad(X, dY, Pk, g, S, s, tm, Pbias, in_place ? NK : stride, mode);
     if (hook) hook->end(code);
     if (!in_place) {
         if (dB == dW + NK) {
@@ -377,7 +379,7 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
 // `g` is the FORWARD geometry.  mask != null applies the ReLU (and dropout scale) backward of the
 // layer's input in the epilogue; accumulate adds into dX (second consumer of a tensor).
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
-                        float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws, size_t sk_floats) {
+                        float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws, size_t sk_floats, int mode) {
     const int N = g.Cout;
     if (ilog2_exact(N) < 4) {   // output layer: K_dgrad = classes (10/11/35) -- tiny VALU kernel
         CMOOP_REQUIRE(g.KH == 1 && g.H == 1 && g.W == 1 && !accumulate, "non power-of-two C_out only supported for dense layers");
@@ -396,6 +398,7 @@ void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGe
         gd.OH = g.OH; gd.OW = g.OW; gd.KH = gd.KW = 1; gd.pad_t = gd.pad_l = 0;
         e.out_stride = g.stride; e.OHf = g.H; e.OWf = g.W;
     }
+    e.mode = mode;
     e.accumulate = accumulate;
     e.mask = mask;
     e.mask_scale = mask_scale;
@@ -416,18 +419,21 @@ void Net::drain_profile() {
     for (size_t i = 0; i < ev_used_; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev_pool_[i].t.start, ev_pool_[i].t.stop) == hipSuccess) {
+            // instantiation names as rocprofv3 prints them (codes: launch_igemm_fwd / launch_igemm_wgrad)
             const int code = ev_pool_[i].code;
-            const int bm = code / 100000, bn = (code / 100) % 1000, bk = code % 100;
-            const int wm = (bm == bn) ? 2 : 4;   // wave layout of each instantiation (gemm.hip)
-            static const int x3 = [] {
-                const char* e = std::getenv("CMOOP_GEMM_MODE");
-                return !e ? 0 : (std::string(e) == "bf16x3" ? 2 : (std::string(e) == "bf16x3r" ? 1 : 0));
-            }();
-            const int mode = bk == 32 ? x3 : 0;
-            const std::string name = ev_pool_[i].cls == 0
-                ? "igemm_fwd_kernel<" + std::to_string(bm) + ", " + std::to_string(bn) + ", " + std::to_string(bk) + ", " +
-                      std::to_string(wm) + ", " + std::to_string(mode) + ">"
-                : "igemm_wgrad_kernel<" + std::to_string(code / 1000) + ", " + std::to_string(code % 1000) + ">";
+            std::string name;
+            if (ev_pool_[i].cls == 0) {
+                const int mode = code / 100000000, c = code % 100000000;
+                const int bm = c / 100000, bn = (c / 100) % 1000, bk = c % 100;
+                const int wm = (bm == bn) ? 2 : 4;   // wave layout of each instantiation (gemm.hip)
+                name = "igemm_fwd_kernel<" + std::to_string(bm) + ", " + std::to_string(bn) + ", " + std::to_string(bk) + ", " +
+                       std::to_string(wm) + ", " + std::to_string(mode) + ">";
+            } else {
+                const int mode = code / 1000000, c = code % 1000000;
+                const std::string tile = std::to_string(c / 1000) + ", " + std::to_string(c % 1000);
+                name = mode == GEMM_FP32 ? "igemm_wgrad_kernel<" + tile + ">"
+                                         : "igemm_wgrad_bf16_kernel<" + tile + ", " + (mode == GEMM_BF16X3 ? "3" : "1") + ">";
+            }
             ProfileEntry& e = t.by_kernel[name];
             e.ms += ms;
             e.flops += ev_pool_[i].flops;
@@ -449,6 +455,7 @@ void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool 
         case OP_CONV:
         case OP_DENSE: {
             GemmEpilogue e;
+            e.mode = op.gemm_mode;
             e.bias = params_ + op.b_off;
             e.relu = op.relu;
             if (train && op.dropout_layer >= 0) {
@@ -505,10 +512,10 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B) {
             const ConvGeom g = geom_of(op, B);
             const float* dY = acts_[op.out].grad;
             Act& ia = acts_[op.in];
-            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, red_ws_, stream_, this);
+            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, red_ws_, stream_, this, op.gemm_mode);
             if (op.need_dgrad)
                 conv_backward_data(dY, params_ + op.w_off, ia.grad, g, wd_ws_, op.in_is_relu ? ia.data : nullptr,
-                                   op.in_mask_scale, op.dgrad_accumulate, stream_, this, splitk_ws_, splitk_ws_floats_);
+                                   op.in_mask_scale, op.dgrad_accumulate, stream_, this, splitk_ws_, splitk_ws_floats_, op.gemm_mode);
             break;
         }
         case OP_BN: {

@@ -34,6 +34,9 @@ from . import _lib, genes as G
 
 FPR_CODES = {"v1": 0, "v1_quirk": 1, "v3": 2}
 ACC_CODES = {"last": 0, "evaluate": 1}
+# arithmetic of the MFMA GEMMs: "fp32" (the reference's, exact fp32 MFMA; CMOOP_GEMM_MODE may override for experiments),
+# "bf16x3" (fp32 operands split exactly into 3 bf16: fp32-accurate, not bit-exact), "bf16" (BASELINE configs[4])
+GEMM_CODES = {"fp32": 0, "bf16x3": 2, "bf16": 3}
 
 
 @dataclass(frozen=True)
@@ -55,6 +58,7 @@ class EvalConfig:
     n_slots: int = 8              # candidates in flight per GPU (each on its own HIP stream)
     eval_batch: int = 256
     profile_every: int = 0
+    compute: str = "fp32"       # GEMM_CODES: arithmetic of the conv/dense MFMA kernels
     lr: float = 1e-3
     dropout: float = 0.3
     shuffle: bool = True
@@ -95,6 +99,7 @@ class EvalConfig:
         c.shuffle = int(self.shuffle)
         c.eval_batch, c.n_slots, c.profile_every = self.eval_batch, self.n_slots, self.profile_every
         c.lr, c.dropout = self.lr, self.dropout
+        c.gemm_mode = GEMM_CODES[self.compute]
         return c
 
 

@@ -34,6 +34,14 @@ extern "C" {
 #define CMOOP_FPR_V1_QUIRK 1 /* V1 with y_true = argmax of an (N,1) array == zeros, nsga_penalty.py:387 */
 #define CMOOP_FPR_V3 2       /* ablation_study/sa_nsga_local.py:138-141 */
 
+/* arithmetic of the MFMA conv/dense GEMM kernels (first conv, C_in = 1, and the classifier layer are always fp32).
+ * The reference trains in fp32 (TF default, no mixed-precision policy set anywhere); DEFAULT/FP32 is that.
+ * BF16X3 and BF16 are opt-in: BF16X3 = fp32 operands split exactly into 3 bf16, six bf16 MFMA terms
+ * (fp32-accurate); BF16 = operands rounded to bf16, fp32 accumulation (BASELINE.json configs[4] "bf16 train"). */
+#define CMOOP_GEMM_DEFAULT 0 /* exact fp32 unless the environment variable CMOOP_GEMM_MODE=bf16x3|bf16 overrides */
+#define CMOOP_GEMM_BF16X3 2
+#define CMOOP_GEMM_BF16 3
+
 /* Evaluation protocol: the module-level constants the reference's evaluate_individual
  * closes over (nsga_penalty.py:176-179) plus the Keras defaults it relies on. */
 typedef struct cmoop_config {
@@ -50,7 +58,7 @@ typedef struct cmoop_config {
     int32_t eval_batch;    /* rows per inference launch (results do not depend on it) */
     int32_t n_slots;       /* candidates in flight per GPU, each on its own HIP stream */
     int32_t profile_every; /* >0: HIP-event-time the MFMA GEMM launches of every n-th train step */
-    int32_t reserved;
+    int32_t gemm_mode;     /* CMOOP_GEMM_*: arithmetic of the MFMA conv/dense GEMMs (0 = library default = exact fp32) */
     double lr;             /* 1e-3: optimizer='adam' (:377); LEARNING_RATE (:162) is unused by the reference */
     double beta1, beta2, adam_eps; /* Keras Adam defaults .9 / .999 / 1e-7 */
     double bn_eps, bn_momentum;    /* Keras BatchNormalization defaults 1e-3 / .99 */

@@ -56,6 +56,34 @@ class OracleConfig:
     bn_momentum: float = 0.99
     dropout: float = 0.3         # code says 0.3 (:323); the docstring's 0.2 is stale
     shuffle: bool = True
+    # "fp32": the reference's arithmetic.  "bf16": the build's own opt-in bf16-train mode (BASELINE configs[4]; no
+    # reference counterpart): conv/dense GEMM operands of every layer between the first conv and the classifier
+    # are rounded to bf16 (round-to-nearest-even) in forward, dgrad and wgrad, products accumulate in fp32.
+    compute: str = "fp32"
+
+
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _Bf16Conv(torch.autograd.Function):
+    """y = conv_same(q(x), q(w)) + b;  dx = dgrad(q(dy), q(w));  dw = wgrad(q(x), q(dy));  db = sum(dy)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride):
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return conv_same(bf16_round(x), bf16_round(w), b, stride)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        with torch.enable_grad():
+            xq = bf16_round(x.detach()).requires_grad_(True)
+            wq = bf16_round(w.detach()).requires_grad_(True)
+            y = conv_same(xq, wq, None, ctx.stride)
+            dx, dw = torch.autograd.grad(y, (xq, wq), bf16_round(g))
+        return dx, dw, g.sum(dim=(0, 2, 3)), None
 
 
 def _same_pad(n, k, s):
@@ -197,7 +225,17 @@ class OracleNet:
         return x * inv[None, :, None, None] + (b - mean * inv)[None, :, None, None]
 
     def _conv(self, x, name, stride=1):
-        return conv_same(x, self.T[name + "/kernel"], self.T[name + "/bias"], stride)
+        w, b = self.T[name + "/kernel"], self.T[name + "/bias"]
+        if self.cfg.compute == "bf16" and w.shape[3] > 1:       # the C_in = 1 first conv stays fp32
+            return _Bf16Conv.apply(x, w, b, stride)
+        return conv_same(x, w, b, stride)
+
+    def _dense(self, x, name):
+        """hidden Dense layers (the classifier layer stays fp32 in every mode)"""
+        w, b = self.T[name + "/kernel"], self.T[name + "/bias"]
+        if self.cfg.compute == "bf16":
+            return _Bf16Conv.apply(x[:, :, None, None], w[:, None, None, :], b, 1)[:, :, 0, 0]
+        return x @ w.t() + b
 
     def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
         """x [B,T,F] float32 -> softmax probabilities [B,classes]."""
@@ -237,7 +275,7 @@ class OracleNet:
             x = F.relu(y + skip)
         x = x.mean(dim=(2, 3))
         for li, name in enumerate(self.fc_names):
-            x = F.relu(x @ self.T[name + "/kernel"].t() + self.T[name + "/bias"])
+            x = F.relu(self._dense(x, name))
             if dr and train:
                 keep = orng.dropout_keep(self.seed, li, self.step, x.shape[0], x.shape[1], self.cfg.dropout)
                 scale = np.float32(1.0 / (1.0 - self.cfg.dropout))

@@ -4,6 +4,7 @@ Floating-point kernels: tolerance is stated per test (fp32 accumulation in a
 different order than the CPU reference; relative to the tensor's max magnitude).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -16,6 +17,18 @@ from oracle.net import conv_same, maxpool_same
 pytestmark = pytest.mark.gpu
 
 TOL = 2e-5   # fp32 GEMM, K <= 12800: |err| <= TOL * max|ref| (MFMA is an exact fmaf chain)
+
+
+# CMOOP_GEMM_MODE=bf16 (child-process test at the bottom): the MFMA kernels round their operands to bf16, and so do
+# the references here; everything that is not an MFMA GEMM (C_in = 1 conv, N % 4 != 0 wgrad, small dgrad, bias sums)
+# stays exact fp32.  Products of bf16 values are exact in fp32, so the tolerances do not change.
+ENV_MODE = os.environ.get("CMOOP_GEMM_MODE", "")
+
+
+def q(x, on=True):
+    if ENV_MODE != "bf16" or not on:
+        return x
+    return torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).to(torch.float32).numpy()
 
 
 def rel(a, b):
@@ -64,7 +77,7 @@ def test_conv_fwd(B, H, W, Cin, Cout, KS, stride, relu):
     xd, wd, bd = dev(x), dev(w), dev(b)
     torch.cuda.synchronize()
     _lib.check(_lib.lib().cmoop_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), B, H, W, Cin, Cout, KS, stride, relu))
-    ref = conv_ref(x, w, b, stride, relu)
+    ref = conv_ref(q(x, Cin > 1), q(w, Cin > 1), b, stride, relu)
     e = rel(y.cpu().numpy(), ref)
     print(f"conv_fwd {B,H,W,Cin,Cout,KS,stride} rel={e:.2e}")
     assert e < TOL
@@ -92,13 +105,20 @@ def test_conv_bwd(B, H, W, Cin, Cout, KS, stride, mask):
     w = (rs.randn(Cout, KS, KS, Cin) / np.sqrt(KS * KS * Cin)).astype(np.float32)
     OH, OW = -(-H // stride), -(-W // stride)
     dy = rs.randn(B, OH, OW, Cout).astype(np.float32)
-    # reference: autograd through relu(pre) where x = relu(pre): grad wrt pre = grad wrt x * (x > 0)
-    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
-    wt = torch.from_numpy(w).clone().requires_grad_(True)
-    bt = torch.zeros(Cout, requires_grad=True)
-    y = conv_same(xt, wt, bt, stride)
-    y.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
-    dx_ref = xt.grad.permute(0, 2, 3, 1).numpy()
+    # reference: autograd through relu(pre) where x = relu(pre): grad wrt pre = grad wrt x * (x > 0).
+    # Two passes so that (bf16 mode) dgrad sees q(dy), q(w) and wgrad sees q(x), q(dy), each only where the MFMA
+    # kernel runs: dgrad needs a power-of-two C_out >= 16, the bf16 wgrad C_out % 4 == 0.
+    q_dx, q_dw = (Cout & (Cout - 1)) == 0 and Cout >= 16, Cout % 4 == 0
+
+    def grads(xn, wn, dyn):
+        xt = torch.from_numpy(xn).permute(0, 3, 1, 2).clone().requires_grad_(True)
+        wt = torch.from_numpy(wn).clone().requires_grad_(True)
+        bt = torch.zeros(Cout, requires_grad=True)
+        conv_same(xt, wt, bt, stride).backward(torch.from_numpy(dyn).permute(0, 3, 1, 2))
+        return xt.grad.permute(0, 2, 3, 1).numpy(), wt.grad.numpy(), bt.grad.numpy()
+    dx_ref, _, db_ref = grads(x, q(w, q_dx), q(dy, q_dx))
+    _, dw_ref, _ = grads(q(x, q_dw), w, q(dy, q_dw))
+    _, _, db_ref = grads(x, w, dy)
     if mask:
         dx_ref = dx_ref * (x > 0)
     dx = torch.full((B, H, W, Cin), float("nan"), device="cuda")
@@ -108,7 +128,7 @@ def test_conv_bwd(B, H, W, Cin, Cout, KS, stride, mask):
     torch.cuda.synchronize()
     _lib.check(_lib.lib().cmoop_conv_bwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(dyd), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
                                          B, H, W, Cin, Cout, KS, stride, mask))
-    e_dx, e_dw, e_db = rel(dx.cpu().numpy(), dx_ref), rel(dw.cpu().numpy(), wt.grad.numpy()), rel(db.cpu().numpy(), bt.grad.numpy())
+    e_dx, e_dw, e_db = rel(dx.cpu().numpy(), dx_ref), rel(dw.cpu().numpy(), dw_ref), rel(db.cpu().numpy(), db_ref)
     print(f"conv_bwd {B,H,W,Cin,Cout,KS,stride} dx={e_dx:.2e} dw={e_dw:.2e} db={e_db:.2e}")
     assert e_dx < TOL and e_dw < 5e-5 and e_db < 5e-5
 
@@ -165,7 +185,7 @@ def test_conv_fwd_full_size_rows():
     torch.cuda.synchronize()
     _lib.check(_lib.lib().cmoop_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), B, H, W, Cin, Cout, KS, 1, 0))
     yh = y.cpu().numpy()
-    ref = conv_ref(x[[0, 63]], w, b, 1, 0)
+    ref = conv_ref(q(x[[0, 63]]), q(w), b, 1, 0)
     assert rel(yh[[0, 63]], ref) < TOL
     # linearity in the input: conv(2x) - bias == 2 (conv(x) - bias)
     x2 = dev(2 * x)
@@ -215,14 +235,14 @@ def test_frontend_edge_cases():
     assert fe.log_mel(torch.zeros((0, 16000), device="cuda")).shape == (0, 101, 40)
 
 
-def test_bf16x3_mode_meets_the_same_tolerance():
-    """The opt-in split-precision GEMM body (CMOOP_GEMM_MODE=bf16x3) is read once per process, so it is
-    exercised in a child process: conv fwd + bwd parity at the exact path's tolerances."""
-    import os
+@pytest.mark.skipif(ENV_MODE != "", reason="already inside a mode-forced child run")
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_bf16_modes_meet_the_same_tolerance(mode):
+    """The opt-in bf16 matrix-core GEMM bodies (CMOOP_GEMM_MODE, read once per process) are exercised in a child
+    process: conv fwd + bwd parity at the exact path's tolerances (bf16: against bf16-rounded operands)."""
     import subprocess
     import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CMOOP_GEMM_MODE="bf16x3")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-q", "-x",
+    env = dict(os.environ, CMOOP_GEMM_MODE=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x",
                         "-k", "test_conv_fwd or test_conv_bwd"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

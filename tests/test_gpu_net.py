@@ -4,6 +4,10 @@ The oracle (oracle/net.py) takes gradients from torch autograd, so these tests
 check every hand-written backward kernel.  fp32 everywhere; tolerances are
 relative to each tensor's max magnitude and stated at the assert.
 """
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -16,8 +20,15 @@ from oracle import net as ON
 pytestmark = pytest.mark.gpu
 
 
+# CMOOP_GEMM_MODE (read once by the library) switches the arithmetic of the MFMA GEMMs for a whole process; the
+# child-process tests at the bottom re-run this file under it.  bf16x3 is fp32-accurate (oracle unchanged); bf16
+# rounds GEMM operands, which the oracle restates (OracleConfig.compute).
+ENV_MODE = os.environ.get("CMOOP_GEMM_MODE", "")
+
+
 def ocfg(cfg: EvalConfig) -> ON.OracleConfig:
-    return ON.OracleConfig(variant=G.VARIANT_NAMES[cfg.variant], classes=cfg.classes, epochs=cfg.epochs, batch=cfg.batch,
+    compute = "bf16" if (cfg.compute == "bf16" or (cfg.compute == "fp32" and ENV_MODE == "bf16")) else "fp32"
+    return ON.OracleConfig(compute=compute, variant=G.VARIANT_NAMES[cfg.variant], classes=cfg.classes, epochs=cfg.epochs, batch=cfg.batch,
                            patience=cfg.patience, early_stop=cfg.early_stop, restore_best=cfg.restore_best,
                            acc_readout="last" if cfg.acc_readout == "last" else "evaluate",
                            fpr_variant=OM.FPR_V1 if cfg.fpr_variant == "v1" else (OM.FPR_V1_QUIRK if cfg.fpr_variant == "v1_quirk" else OM.FPR_V3),
@@ -265,3 +276,59 @@ def test_hypervolume_parity_gpu_vs_oracle_search():
         hv_g, hv_c = nsga.hypervolume(f_gpu[g], ref), nsga.hypervolume(f_cpu[g], ref)
         print(f"gen {g}: HV gpu {hv_g:.6f} oracle {hv_c:.6f}")
         assert abs(hv_g - hv_c) <= 0.01 * max(hv_c, 1e-12)
+
+
+def _cos(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+def test_bf16_modes_selected_by_config_field():
+    """EvalConfig(compute=...) (cmoop_config.gemm_mode, no environment variable), one training step.
+
+    bf16x3 is fp32-accurate: same 5e-4 gate as the exact path (observed 2e-6 .. 4e-6).
+
+    bf16 rounds the GEMM operands of every layer between the first conv and the classifier (forward, dgrad, wgrad;
+    fp32 accumulation), which the oracle restates (OracleConfig.compute='bf16').  The KERNELS match that definition
+    at the fp32 tolerance (tests/test_gpu_kernels.py under CMOOP_GEMM_MODE=bf16: products of bf16 values are exact
+    in fp32).  A whole net cannot be gated that tightly: a 1e-7 difference in an fp32 sum flips bf16 roundings
+    downstream, and the bf16 oracle differs FROM ITSELF by 1.6e-2 .. 1.4e-1 (same metric) when only torch's CPU conv
+    algorithm changes (mkldnn vs native; measured).  So the gates are: loss within 1e-3, the full
+    gradient vector within cos >= 0.995 of the bf16 oracle's, and closer to it than to the fp32 oracle's."""
+    classes, seed, T, F, B = 10, 99, 21, 12, 24
+    X, y = make_data(64, T, F, classes, 3)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    for gene in [(32, 5, 1, 2, 3, 1), (32, 5, 0, 2, 3, 1), (16, 3, 1, 1, 2, 1)]:
+        o32 = ON.OracleNet(gene, ocfg(EvalConfig(variant="A", classes=classes, batch=32, compute="bf16x3")), seed)
+        o32.train_step(X[8:8 + B], y[8:8 + B])
+        for compute in ("bf16x3", "bf16"):
+            cfg = EvalConfig(variant="A", classes=classes, batch=32, eval_batch=16, compute=compute)
+            onet = ON.OracleNet(gene, ocfg(cfg), seed)
+            assert onet.cfg.compute == ("bf16" if compute == "bf16" else "fp32")
+            with NetSession(gene, cfg, T, F, seed) as net:
+                net.train_step(Xd, yd, None, row0=8, B=B)
+                lo, co = onet.train_step(X[8:8 + B], y[8:8 + B])
+                lg, cg = net.train_metrics()
+                g, go, g32 = net.get_grads(), onet.grads_flat(), o32.grads_flat()
+                gerr = per_tensor_err(gene, 0, classes, g, go)
+                print(f"{gene} compute={compute}: loss {lg:.6f} / {lo:.6f}; worst tensor err {max(gerr.values()):.2e}; "
+                      f"cos own oracle {_cos(g, go):.6f}, cos fp32 oracle {_cos(g, g32):.6f}")
+                if compute == "bf16x3":
+                    assert abs(lg - lo) < 2e-5 * max(1.0, abs(lo)) and max(gerr.values()) < 5e-4, gerr
+                else:
+                    assert abs(lg - lo) < 1e-3 * max(1.0, abs(lo))
+                    assert _cos(g, go) >= 0.995 and _cos(g, go) > _cos(g, g32)
+                l_o, a_o, p_o = onet.evaluate(X, y)
+                l_g, a_g, p_g = net.evaluate(Xd, yd)
+                assert abs(l_g - l_o) < 2e-3 * max(1.0, abs(l_o))
+
+
+@pytest.mark.skipif(ENV_MODE != "", reason="already inside a mode-forced child run")
+def test_net_parity_under_forced_bf16x3():
+    """Re-run the gradient / inference / protocol parity tests of this file in a child process with
+    CMOOP_GEMM_MODE=bf16x3 (every MFMA GEMM of every net on the split-precision bodies): the exact path's gates."""
+    env = dict(os.environ, CMOOP_GEMM_MODE="bf16x3")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "test_init_step_grads_and_eval_parity or test_partial_batch or test_classes_35 or "
+                        "test_evaluate_individual_protocol_parity"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
