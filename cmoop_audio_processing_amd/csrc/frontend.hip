@@ -1,4 +1,4 @@
-// Audio front end: framing -> Hann -> 512-pt FFT -> |.|^2 -> sparse Slaney mel -> log.
+// Audio front end: framing -> Hann -> 512-pt real FFT -> |.|^2 -> sparse Slaney mel -> log.
 // North-star addition beneath the reference's data loader (the reference ships
 // pre-extracted features only: nsga_penalty.py:64-71); the
 // algorithm restates librosa.feature.melspectrogram (requirements.txt:80) and is
@@ -6,12 +6,17 @@
 //
 // One 256-thread workgroup per clip, each wave owns one frame at a time.  A frame is one
 // coalesced 2 KB segment of the clip; the 3.2x overlap between consecutive frames is served
-// by L2, so HBM sees each clip once (64 000 B in, T*n_mels*4 B out).  The twiddle table, the
-// window and the sparse mel weights are LDS-resident; each wave runs its radix-2 FFT in its
-// own LDS scratch with wave-level synchronisation only (25 KB LDS per workgroup, 6 per CU).
-// Measured 10.3 ms for 30 000 clips = 234 GB/s algorithmic (3 % of the HBM roofline): the
-// radix-2 LDS FFT, not HBM, bounds it; it runs once per dataset.
+// by L2, so HBM sees each clip once (64 000 B in, T*n_mels*4 B out).
+// The 512 real samples are packed into 256 complex points (even + i*odd) and transformed by a
+// 256-point radix-4 decimation-in-frequency FFT held in registers: each lane owns one radix-4
+// butterfly per stage (4 stages), with three exchanges through the wave's own LDS scratch
+// (padded so every ds_read/write_b64 is conflict-free) and every twiddle / window value
+// precomputed per lane in registers outside the frame loop.  The real-FFT split
+// X[k] = E[k] + W^k O[k] follows in LDS-skewed natural order, then the sparse mel: each band is one
+// lane's short loop, the widest bands split over two lanes, summed in fixed order.
+// Only wave-level synchronisation (LDS operations of one wave complete in issue order).
 #include "kernels.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -23,7 +28,7 @@ struct FrontendTables {
     float* tw = nullptr;       // [n_fft/2][2] cos, -sin
     float* win = nullptr;      // [n_fft] padded periodic Hann
     float* melw = nullptr;     // sparse weights, band after band
-    int* meloff = nullptr;     // [n_mels][2] first bin, count ; prefix offset in [2*n_mels ..]
+    int* meltask = nullptr;    // [64][3] first bin, count, weight offset of each lane's task ; then [64] second task of a band or -1
     int nnz = 0;
 };
 
@@ -55,11 +60,11 @@ FrontendTables* frontend_tables_create(const FrontendCfg& c) {
     const double m_lo = hz_to_mel(c.fmin), m_hi = hz_to_mel(c.fmax);
     for (int i = 0; i < c.n_mels + 2; ++i) mel_f[i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (c.n_mels + 1));
     std::vector<float> w;
-    std::vector<int> off(3 * c.n_mels);
+    std::vector<int> first_bin(c.n_mels), count(c.n_mels), start(c.n_mels);
     for (int i = 0; i < c.n_mels; ++i) {
         const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
-        int first = -1, count = 0;
-        const int start = (int)w.size();
+        int first = -1, cnt = 0;
+        start[i] = (int)w.size();
         for (int b = 0; b < nb; ++b) {
             const double f = (double)b * (c.sr / 2.0) / half;
             const double lower = (f - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
@@ -67,129 +72,198 @@ FrontendTables* frontend_tables_create(const FrontendCfg& c) {
             const double v = std::max(0.0, std::min(lower, upper)) * enorm;
             if (v > 0.0) {
                 if (first < 0) first = b;
-                // bins of one triangle are contiguous
-                w.push_back((float)v);
-                ++count;
+                w.push_back((float)v);     // bins of one triangle are contiguous
+                ++cnt;
             }
         }
-        off[2 * i] = first < 0 ? 0 : first;
-        off[2 * i + 1] = count;
-        off[2 * c.n_mels + i] = start;
+        first_bin[i] = first < 0 ? 0 : first;
+        count[i] = cnt;
+    }
+    // lane tasks: task i < n_mels = band i; the spare lanes take the second half of the widest bands
+    std::vector<int> task(64 * 3 + 64, 0);
+    for (int i = 0; i < 64; ++i) task[192 + i] = -1;
+    for (int i = 0; i < c.n_mels; ++i) { task[3 * i] = first_bin[i]; task[3 * i + 1] = count[i]; task[3 * i + 2] = start[i]; }
+    std::vector<int> order(c.n_mels);
+    for (int i = 0; i < c.n_mels; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return count[a] > count[b]; });
+    int next = c.n_mels;
+    for (int oi = 0; oi < c.n_mels && next < 64; ++oi) {
+        const int b = order[oi];
+        if (count[b] < 8) break;
+        const int h = count[b] / 2;                  // first task keeps bins [0, h), second [h, count)
+        task[3 * b + 1] = h;
+        task[3 * next] = first_bin[b] + h; task[3 * next + 1] = count[b] - h; task[3 * next + 2] = start[b] + h;
+        task[192 + b] = next;
+        ++next;
     }
     t->nnz = (int)w.size();
     if (w.empty()) w.push_back(0.f);
     CMOOP_HIP(hipMalloc(&t->tw, tw.size() * 4));
     CMOOP_HIP(hipMalloc(&t->win, win.size() * 4));
     CMOOP_HIP(hipMalloc(&t->melw, w.size() * 4));
-    CMOOP_HIP(hipMalloc(&t->meloff, off.size() * 4));
+    CMOOP_HIP(hipMalloc(&t->meltask, task.size() * 4));
     CMOOP_HIP(hipMemcpy(t->tw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
     CMOOP_HIP(hipMemcpy(t->win, win.data(), win.size() * 4, hipMemcpyHostToDevice));
     CMOOP_HIP(hipMemcpy(t->melw, w.data(), w.size() * 4, hipMemcpyHostToDevice));
-    CMOOP_HIP(hipMemcpy(t->meloff, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    CMOOP_HIP(hipMemcpy(t->meltask, task.data(), task.size() * 4, hipMemcpyHostToDevice));
     CMOOP_REQUIRE(t->nnz <= 1024, "front end: mel table too large");
     return t;
 }
 
 void frontend_tables_destroy(FrontendTables* t) {
     if (!t) return;
-    hipFree(t->tw); hipFree(t->win); hipFree(t->melw); hipFree(t->meloff);
+    hipFree(t->tw); hipFree(t->win); hipFree(t->melw); hipFree(t->meltask);
     delete t;
 }
 
-constexpr int NFFT = 512, LOG2N = 9, MAXCLIP = 16384;
+constexpr int NFFT = 512, NC = 256;   // real points, packed complex points
 
-// Each wave owns its re/im scratch, so the FFT stages only need the wave's own LDS writes to be
-// visible to its other lanes: LDS operations of one wave complete in issue order; the fences only
-// stop the compiler from moving the reads above the writes.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Each wave owns its scratch, so the phases only need the wave's own LDS writes to be visible to its
+// other lanes: LDS operations of one wave complete in issue order; the fences only stop the compiler
+// from moving the reads above the writes.
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+__device__ __forceinline__ f32x2 cmul(const f32x2 a, const f32x2 w) {
+    return f32x2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
+}
+// radix-4 forward butterfly: b_j = sum_p a_p (-i)^(p j)
+__device__ __forceinline__ void bfly4(const f32x2 a0, const f32x2 a1, const f32x2 a2, const f32x2 a3, f32x2& b0, f32x2& b1,
+                                      f32x2& b2, f32x2& b3) {
+    const f32x2 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    const f32x2 nid = f32x2{d13.y, -d13.x};   // -i * d13
+    b0 = s02 + s13;
+    b2 = s02 - s13;
+    b1 = d02 + nid;
+    b3 = d02 - nid;
+}
 
-template <bool CLIP_IN_LDS>
 __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wav, int n_samples, float* __restrict__ out,
                                                      int T, int hop, int n_mels, float log_eps,
                                                      const float* __restrict__ g_tw, const float* __restrict__ g_win,
-                                                     const float* __restrict__ g_melw, const int* __restrict__ g_meloff,
+                                                     const float* __restrict__ g_melw, const int* __restrict__ g_task,
                                                      int nnz) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_tw = smem;                        // 512
-    float* s_win = s_tw + NFFT;                // 512
-    float* s_melw = s_win + NFFT;              // 1024
-    float* s_re = s_melw + 1024;               // 4 * 512
-    float* s_im = s_re + 4 * NFFT;             // 4 * 512
-    int* s_off = reinterpret_cast<int*>(s_im + 4 * NFFT);   // 192
-    float* s_clip = reinterpret_cast<float*>(s_off + 192);  // n_samples (when CLIP_IN_LDS)
+    constexpr int XB = 320;    // complex slots of the exchange buffer (pitch-20 / pitch-5 layouts, skewed spectrum)
+    constexpr int PB = 264;    // power spectrum bins 0..256
+    __shared__ float s_melw[1024];
+    __shared__ int s_task[256];
+    __shared__ __attribute__((aligned(16))) f32x2 s_x[4][XB];
+    __shared__ float s_p[4][PB];
+    __shared__ float s_part[4][64];
 
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const float* clip = wav + (size_t)blockIdx.x * n_samples;
-    for (int i = t; i < NFFT; i += 256) { s_tw[i] = g_tw[i]; s_win[i] = g_win[i]; }
     for (int i = t; i < nnz; i += 256) s_melw[i] = g_melw[i];
-    for (int i = t; i < 3 * n_mels; i += 256) s_off[i] = g_meloff[i];
-    if (CLIP_IN_LDS) {
-        const int n4 = n_samples >> 2;
-        for (int i = t; i < n4; i += 256)
-            *reinterpret_cast<float4*>(s_clip + 4 * i) = *reinterpret_cast<const float4*>(clip + 4 * i);
-        for (int i = 4 * n4 + t; i < n_samples; i += 256) s_clip[i] = clip[i];
-    }
+    s_task[t] = g_task[t];
     __syncthreads();
-    const float* src = CLIP_IN_LDS ? s_clip : clip;
-    float* re = s_re + wave * NFFT;
-    float* im = s_im + wave * NFFT;
+
+    // ---- per-lane constants, fixed over the frames -------------------------------------------------
+    const f32x2* tw = reinterpret_cast<const f32x2*>(g_tw);   // tw[k] = exp(-2 pi i k / 512), k < 256
+    auto tw512 = [&](int k) {                                 // k < 512: W^(k + 256) = -W^k
+        const f32x2 v = tw[k & 255];
+        return (k & 256) ? -v : v;
+    };
+    f32x2 w0[3], w1[3], w2[3], wp[4];
+    float win[8];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        w0[j - 1] = tw512(2 * ((lane * j) & 255));           // W_256^(l j)
+        w1[j - 1] = tw512(8 * (((lane & 15) * j) & 63));     // W_64^(n j),  n = l & 15
+        w2[j - 1] = tw512(32 * (((lane & 3) * j) & 15));     // W_16^(n j),  n = l & 3
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        wp[u] = tw[lane + 64 * u];                            // W_512^k, k = lane + 64 u
+        win[2 * u] = g_win[2 * (lane + 64 * u)];
+        win[2 * u + 1] = g_win[2 * (lane + 64 * u) + 1];
+    }
+    const int j1 = lane >> 4, n1 = lane & 15;                 // stage 1: sub-FFT j1 of 64 points, butterfly n1
+    const int s2 = lane >> 2, n2 = lane & 3;                  // stage 2: sub-FFT s2 of 16 points, butterfly n2
+    const int klow = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);   // stage 3: output bins klow + 64 j4
+    const int task_first = s_task[3 * lane], task_cnt = s_task[3 * lane + 1], task_w = s_task[3 * lane + 2];
+    const int task2 = s_task[192 + lane];
+
+    f32x2* xb = s_x[wave];
+    float* pw = s_p[wave];
+    float* part = s_part[wave];
     const int iters = (T + 3) >> 2;
     for (int it = 0; it < iters; ++it) {
         const int frame = it * 4 + wave;
-        const bool live = frame < T;
-        // windowed frame, bit-reversed order (centre-padded with zeros: pad_mode='constant')
-        if (live) {
-            const int base = frame * hop - NFFT / 2;
+        if (frame >= T) break;                                // wave-uniform; no workgroup barrier below
+        // windowed frame, centre-padded with zeros (pad_mode='constant'); z[m] = x[2m] + i x[2m+1]
+        const int base = frame * hop - NFFT / 2;
+        f32x2 a[4], b[4];
 #pragma unroll
-            for (int u = 0; u < NFFT / 64; ++u) {
-                const int i = lane + 64 * u;
-                const int sidx = base + i;
-                float v = 0.f;
-                const float w = s_win[i];
-                if (w != 0.f && sidx >= 0 && sidx < n_samples) v = src[sidx] * w;
-                const int r = (int)(__brev((unsigned)i) >> (32 - LOG2N));
-                re[r] = v;
-                im[r] = 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const int i0 = base + 2 * (lane + 64 * u);
+            const float x0 = (i0 >= 0 && i0 < n_samples) ? clip[i0] : 0.f;
+            const float x1 = (i0 + 1 >= 0 && i0 + 1 < n_samples) ? clip[i0 + 1] : 0.f;
+            a[u] = f32x2{x0 * win[2 * u], x1 * win[2 * u + 1]};
+        }
+        // stage 0: points l + 64 p  ->  four 64-point sequences y_j[l]
+        bfly4(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
+        xb[lane] = b[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) xb[64 * j + lane] = cmul(b[j], w0[j - 1]);
+        wave_sync();
+        // stage 1: y_j[n + 16 p] -> sixteen 16-point sequences, stored with pitch 20
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a[p] = xb[64 * j1 + n1 + 16 * p];
+        wave_sync();
+        bfly4(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
+        xb[(4 * j1) * 20 + n1] = b[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) xb[(4 * j1 + j) * 20 + n1] = cmul(b[j], w1[j - 1]);
+        wave_sync();
+        // stage 2: u[n + 4 p] -> sixty-four 4-point sequences, stored with pitch 5
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a[p] = xb[20 * s2 + n2 + 4 * p];
+        wave_sync();
+        bfly4(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
+        xb[(4 * s2) * 5 + n2] = b[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) xb[(4 * s2 + j) * 5 + n2] = cmul(b[j], w2[j - 1]);
+        wave_sync();
+        // stage 3: 4-point transforms; Z[k], k = klow + 64 j4, stored in natural order skewed by k >> 4
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a[p] = xb[5 * lane + p];
+        wave_sync();
+        bfly4(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = klow + 64 * j;
+            xb[k + (k >> 4)] = b[j];
+        }
+        wave_sync();
+        // real-FFT split and power spectrum: X[k] = E[k] + W_512^k O[k], E = (Z[k] + conj Z[256-k]) / 2, O = (Z[k] - conj Z[256-k]) / 2i
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = lane + 64 * u, kc = (NC - k) & (NC - 1);
+            const f32x2 z = xb[k + (k >> 4)], zc = xb[kc + (kc >> 4)];
+            const f32x2 e = f32x2{0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y)};
+            const f32x2 o = f32x2{0.5f * (z.y + zc.y), -0.5f * (z.x - zc.x)};
+            const f32x2 x = e + cmul(o, wp[u]);
+            pw[k] = x.x * x.x + x.y * x.y;
+            if (k == 0) {                                     // bin 256: E[0] - O[0]
+                const float xn = e.x - o.x;
+                pw[NC] = xn * xn;
             }
         }
         wave_sync();
-#pragma unroll 1
-        for (int s = 0; s < LOG2N; ++s) {
-            if (live) {
-                const int half = 1 << s;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = lane + 64 * u;
-                    const int pos = j & (half - 1);
-                    const int i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + half;
-                    const int k = pos << (LOG2N - 1 - s);
-                    const float wr = s_tw[2 * k], wi = s_tw[2 * k + 1];
-                    const float br = re[i1], bi = im[i1];
-                    const float tr = br * wr - bi * wi, ti = br * wi + bi * wr;
-                    const float ar = re[i0], ai = im[i0];
-                    re[i0] = ar + tr; im[i0] = ai + ti;
-                    re[i1] = ar - tr; im[i1] = ai - ti;
-                }
-            }
-            wave_sync();
-        }
-        // power spectrum in place (bins 0..256 kept in re[])
-        if (live) {
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int b = lane + 64 * u;
-                if (b <= NFFT / 2) re[b] = re[b] * re[b] + im[b] * im[b];
-            }
-        }
-        wave_sync();
-        if (live && lane < n_mels) {
-            const int first = s_off[2 * lane], cnt = s_off[2 * lane + 1], wo = s_off[2 * n_mels + lane];
+        // sparse mel: one short loop per lane task, second halves of the widest bands on the spare lanes
+        {
             float acc = 0.f;
-            for (int i = 0; i < cnt; ++i) acc = fmaf(s_melw[wo + i], re[first + i], acc);
+            for (int i = 0; i < task_cnt; ++i) acc = fmaf(s_melw[task_w + i], pw[task_first + i], acc);
+            part[lane] = acc;
+        }
+        wave_sync();
+        if (lane < n_mels) {
+            float acc = part[lane];
+            if (task2 >= 0) acc += part[task2];
             out[((size_t)blockIdx.x * T + frame) * n_mels + lane] = logf(acc + log_eps);
         }
         wave_sync();
@@ -200,26 +274,8 @@ void launch_logmel(const float* wav, int64_t n_clips, int n_samples, float* out,
     if (n_clips == 0) return;
     const FrontendCfg& c = t->cfg;
     const int T = 1 + n_samples / c.hop;
-    const size_t fixed = (NFFT + NFFT + 1024 + 8 * NFFT) * 4 + 192 * 4;
-    // default: frames are read straight from global memory (each 2 KB frame is one coalesced segment and the
-    // 3.2x overlap between frames is served by L2), leaving 25 KB of LDS per workgroup = 6 workgroups per CU;
-    // CMOOP_FE_CLIP_LDS=1 stages the whole clip in LDS instead (1 workgroup per CU)
-    const char* fe = std::getenv("CMOOP_FE_CLIP_LDS");
-    const bool in_lds = fe && fe[0] == '1' && n_samples <= MAXCLIP && (n_samples % 4 == 0);
-    if (in_lds) {
-        const size_t lds = fixed + (size_t)n_samples * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            CMOOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((logmel_kernel<true>), dim3((unsigned)n_clips), dim3(256), lds, s, wav, n_samples, out, T, c.hop,
-                           c.n_mels, c.log_eps, t->tw, t->win, t->melw, t->meloff, t->nnz);
-    } else {
-        hipLaunchKernelGGL((logmel_kernel<false>), dim3((unsigned)n_clips), dim3(256), fixed, s, wav, n_samples, out, T,
-                           c.hop, c.n_mels, c.log_eps, t->tw, t->win, t->melw, t->meloff, t->nnz);
-    }
+    hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)n_clips), dim3(256), 0, s, wav, n_samples, out, T, c.hop, c.n_mels,
+                       c.log_eps, t->tw, t->win, t->melw, t->meltask, t->nnz);
     CMOOP_HIP(hipGetLastError());
 }
 

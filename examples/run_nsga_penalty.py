@@ -10,8 +10,10 @@ against one shared reference point (compare.ipynb semantics).
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/run_nsga_penalty.py --pop 40 --gen 20
 """
 import argparse
+import json
 import os
 import sys
+import time
 
 import torch
 
@@ -28,6 +30,8 @@ def main():
     ap.add_argument("--epochs", type=int, default=300)      # EPOCHS, nsga_penalty.py:177 (early stopping active)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default="nsga_generations.csv")
+    ap.add_argument("--trace", default="", help="write a JSON trace: per evaluate call wall-clock, epochs run, hypervolume")
+    ap.add_argument("--compute", default="fp32", choices=["fp32", "bf16x3", "bf16"])
     a = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -41,14 +45,35 @@ def main():
     Xtr, Xva = feats[:n_tr].contiguous(), feats[n_tr:n_tr + n_va].contiguous()
     frontend.prepare_dataset(Xtr, Xva, None, mode="refit")
     ev = PopulationEvaluator(Xtr, y[:n_tr], Xva, y[n_tr:n_tr + n_va],
-                             EvalConfig.preset("nsga_penalty", epochs=a.epochs, seed=a.seed, verbose=(rank == 0)))
-    pareto, hist = nsga.nsga2(ev.compute_objectives_and_constraints, a.pop, a.gen, seed=a.seed)
+                             EvalConfig.preset("nsga_penalty", epochs=a.epochs, seed=a.seed, verbose=(rank == 0),
+                                               compute=a.compute))
+    calls = []
+    t_start = time.perf_counter()
+
+    def evaluate(population):
+        t0 = time.perf_counter()
+        res = ev.compute_objectives_and_constraints(population)
+        calls.append({"candidates": len(population), "seconds": round(time.perf_counter() - t0, 3),
+                      "wall_clock_s": round(time.perf_counter() - t_start, 3), "epochs_run": list(ev.last_epochs_run)})
+        if rank == 0:
+            print(f"[search] evaluate call {len(calls)}: {len(population)} candidates in {calls[-1]['seconds']} s, "
+                  f"epochs run min/mean/max {min(ev.last_epochs_run)}/{sum(ev.last_epochs_run) / len(population):.1f}/"
+                  f"{max(ev.last_epochs_run)}", file=sys.stderr, flush=True)
+        return res
+    pareto, hist = nsga.nsga2(evaluate, a.pop, a.gen, seed=a.seed)
     if rank == 0:
         nsga.write_records_csv(a.out, hist)
         fronts = [[[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in h] for h in hist]
         ref = nsga.shared_reference_point(fronts)
-        for g, f in enumerate(fronts):
-            print(f"generation {g}: hypervolume {nsga.hypervolume(f, ref):.6f}")
+        hv = [nsga.hypervolume(f, ref) for f in fronts]
+        for g, v in enumerate(hv):
+            print(f"generation {g}: hypervolume {v:.6f}")
+        if a.trace:
+            with open(a.trace, "w") as fh:
+                json.dump({"pop": a.pop, "gen": a.gen, "clips": a.clips, "n_train": n_tr, "max_epochs": a.epochs, "gpus": world,
+                           "compute": a.compute, "reference_point": [float(v) for v in ref], "hypervolume_per_generation": hv,
+                           "evaluate_calls": calls, "true_evaluations": ev.evals_done,
+                           "evals_per_hour": round(ev.evals_done / (calls[-1]["wall_clock_s"] / 3600.0), 1)}, fh)
         print(f"{len(pareto)} feasible Pareto solutions; {ev.evals_done} true evaluations; records -> {a.out}")
     if world > 1:
         torch.distributed.destroy_process_group()
