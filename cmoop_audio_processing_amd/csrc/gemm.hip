@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     constexpr bool PLANES = MODE != GEMM_FP32;
     constexpr int NP = MODE == GEMM_BF16X3 ? 3 : 1;
     constexpr int WN = 4 / WM;
-    constexpr int LDK = BK + 4;
+    constexpr int LDK = BK + 8;    // pitch = 2 (mod 4) sixteen-byte slots: conflict-free ds_read_b128 fragments (16-lane groups, 64 banks)
     constexpr int TPR = BK / 4;
     constexpr int RPP = 256 / TPR;
     constexpr int APASS = (BM + RPP - 1) / RPP;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     constexpr int RT = BM / WM / 16, CT = BN / WN / 16;
     static_assert(RT >= 1 && CT >= 1, "tile too small for the wave layout");
     static_assert(!PLANES || BK == 32, "bf16 planes need 32-deep K chunks");
-    constexpr int LDH = 40;   // bf16 planes: rows of 32 k + 8 pad = 80 B (16-B aligned fragments, conflict-free b128 reads)
+    constexpr int LDH = 48;   // bf16 planes: rows of 32 k + 16 pad = 96 B = 6 slots (conflict-free b128 fragment reads)
     __shared__ __attribute__((aligned(16))) float As[PLANES ? 1 : 2][PLANES ? 4 : BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[PLANES ? 1 : 2][PLANES ? 4 : BN * LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Ah[NP][PLANES ? BM * LDH : 8];
@@ -597,6 +597,9 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
 // The MFMA reduction index is the pixel row m; both operands are read from LDS
 // m-major (ds_read_b32, leading dimension == 16 mod 32 -> conflict-free).
 // grid = (K tiles of 64, N tiles of BCO, S row-slices); partials P[S][N][K].
+// (Measured alternative, not adopted: transposing 4x4 blocks in registers on the way into LDS so that fragments are
+// ds_read_b128 as in the forward kernel -- conflict-free with pitch 40 + XOR swizzle, coalesced gathers -- ran 8 %
+// slower than this m-major image with ds_read_b32 fragments: 95 vs 103 TFLOP/s on 128->128 k5.)
 // ---------------------------------------------------------------------------
 template <int BCO, int BKI>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
@@ -744,8 +747,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
 // but both operands arrive m-major (dY[m][co], im2col(X)[m][k]), so the transposition happens on the way into
 // LDS: a loader thread owns 8 consecutive rows x 4 columns, splits/rounds them, packs row PAIRS into 32-bit
 // words and writes, per plane and column, ONE 16-byte piece = 8 consecutive m of that column -- exactly an MFMA
-// fragment, read back with a single ds_read_b128.  Line pitch 20 words (16 + 4 pad) keeps both the b128
-// stores (lanes ordered row-group fastest) and the fragment reads conflict-free.
+// fragment, read back with a single ds_read_b128.  Lanes are column-quad-fastest (coalesced gathers); line pitch
+// 20 words plus an XOR of the row-group position with (column quad >> 1) & 3 keeps the b128 stores conflict-free
+// (8-lane groups, 32 banks); the fragment reads are 2-way (MI355X_MICROARCH.md, LDS table).
 // Threads [0, BKI) load X, [BKI, BKI + BCO) load dY (wave-uniform roles for the 64/128 tiles).
 // ---------------------------------------------------------------------------
 template <int BCO, int BKI, int NP>
@@ -768,7 +772,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_bf16_kernel(const float* __re
 
     const bool isX = t < BKI, isY = !isX && t < BKI + BCO;
     const int tl = isX ? t : t - BKI;
-    const int rg = tl & 3, cq = tl >> 2;          // row group (rows 8rg..8rg+7 of the chunk), column quad
+    // column quad fastest over lanes (coalesced gathers); row group = rows 8rg..8rg+7 of the chunk
+    const int cq = tl % ((isX ? BKI : BCO) / 4), rg = tl / ((isX ? BKI : BCO) / 4);
+    const int rgs = rg ^ ((cq >> 1) & 3);         // LDS position of the row group: XOR swizzle -> conflict-free b128 stores
     // X role: fixed k index for the block's life
     const int kidx = k0 + 4 * cq;
     const bool kok = isX && kidx < g.K;
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_bf16_kernel(const float* __re
             for (int u = 0; u < 4; ++u) split_pair<NP>(r[2 * u][j], r[2 * u + 1][j], w[u]);
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                *reinterpret_cast<uint4*>(base + pl * plane_words + (4 * cq + j) * PITCH + 4 * rg) =
+                *reinterpret_cast<uint4*>(base + pl * plane_words + (4 * cq + j) * PITCH + 4 * rgs) =
                     make_uint4(w[0][pl], w[1][pl], w[2][pl], w[3][pl]);
         }
     };
@@ -838,16 +844,19 @@ __global__ __launch_bounds__(256) void igemm_wgrad_bf16_kernel(const float* __re
         if (c + 1 < nchunks) load_chunk(mbeg + (c + 1) * MC);
         bf16x8 b[KPW][NP];
 #pragma unroll
-        for (int kt = 0; kt < KPW; ++kt)
+        for (int kt = 0; kt < KPW; ++kt) {
+            const int col = (wave_k * KPW + kt) * 16 + lr;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                b[kt][pl] = *reinterpret_cast<const bf16x8*>(&Xh[pl][((wave_k * KPW + kt) * 16 + lr) * PITCH + 4 * q]);
+                b[kt][pl] = *reinterpret_cast<const bf16x8*>(&Xh[pl][col * PITCH + 4 * (q ^ ((col >> 3) & 3))]);
+        }
 #pragma unroll
         for (int c2 = 0; c2 < CPW; ++c2) {
             bf16x8 a[NP];
+            const int colc = (wave_c * CPW + c2) * 16 + lr;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                a[pl] = *reinterpret_cast<const bf16x8*>(&Yh[pl][((wave_c * CPW + c2) * 16 + lr) * PITCH + 4 * q]);
+                a[pl] = *reinterpret_cast<const bf16x8*>(&Yh[pl][colc * PITCH + 4 * (q ^ ((colc >> 3) & 3))]);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int term = (NP == 3 ? 0 : 5); term < 6; ++term)
@@ -861,7 +870,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_bf16_kernel(const float* __re
 
     if (do_bias) {   // fixed-order reduction over the 4 row groups that share a column quad
         float* red = reinterpret_cast<float*>(&Xh[0][0]);   // >= 4*BCO floats, free after the loop's last barrier
-        if (isY) *reinterpret_cast<f32x4*>(&red[4 * tl]) = bsum;
+        if (isY) *reinterpret_cast<f32x4*>(&red[4 * (4 * cq + rg)]) = bsum;
         __syncthreads();
         if (t < BCO && co0 + t < g.Cout) {
             const int q4 = t >> 2, j = t & 3;
