@@ -496,16 +496,26 @@ static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDe
 }
 
 // Pick a multiplier m in [1, max_mult] for `base` workgroups so that base*m fills whole waves of
-// `resident` co-resident workgroups (256 CUs x workgroups per CU): the smallest m whose last wave is
-// >= 85 % full, else the best-filled one.  Few-wave grids otherwise pay up to 2x for a ragged tail.
-static int fill_waves(long base, int max_mult, int resident) {
+// `resident` co-resident workgroups (256 CUs x workgroups per CU).  Few-wave grids otherwise pay up to 2x for a
+// ragged tail.
+static int fill_waves(long base, int max_mult, int resident, double first_thr = 0.85) {
+    // the smallest multiplier whose last wave is >= first_thr full; failing that >= 85 %; failing that the best-filled
+    // one.  wgrad slices ask for 95 % (a 450-workgroup grid on 512 slots cost the 128->128 k5 wgrad 11 %); forward
+    // split-K keeps 85 % because every extra split adds a slab to write and combine.
+    for (const double thr : {first_thr, 0.85}) {
+        for (int m = 1; m <= max_mult; ++m) {
+            const long blocks = base * m;
+            const long waves = (blocks + resident - 1) / resident;
+            const double u = (double)blocks / (double)(waves * resident);
+            if (blocks >= resident / 2 && u >= thr) return m;
+        }
+    }
     int best = 1;
     double best_u = 0.0;
     for (int m = 1; m <= max_mult; ++m) {
         const long blocks = base * m;
         const long waves = (blocks + resident - 1) / resident;
         const double u = (double)blocks / (double)(waves * resident);
-        if (blocks >= resident / 2 && u >= 0.85) return m;
         if (u > best_u) { best_u = u; best = m; }
     }
     return best;
@@ -697,19 +707,25 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
             for (int p = 0; p < YPASS; ++p) bsum += ry[p];   // ry still holds chunk c (rows past mend are zero)
         }
         if (c + 1 < nchunks) load_chunk(mbeg + (c + 1) * MC);
+        // fragments of step st+1 are read while the MFMAs of step st issue (two register sets): with eight
+        // 4-row steps per chunk an un-pipelined loop exposes the LDS latency eight times per chunk
+        float a[2][CPW], b[2][KPW];
+        auto read_frags = [&](int st, int set) {
+#pragma unroll
+            for (int c2 = 0; c2 < CPW; ++c2) a[set][c2] = Ys[buf][(st * 4 + q) * LDY + (wave_c * CPW + c2) * 16 + lr];
+#pragma unroll
+            for (int kt = 0; kt < KPW; ++kt) b[set][kt] = Xs[buf][(st * 4 + q) * LDX + (wave_k * KPW + kt) * 16 + lr];
+        };
+        read_frags(0, 0);
 #pragma unroll
         for (int st = 0; st < MC / 4; ++st) {
-            float a[CPW], b[KPW];
-#pragma unroll
-            for (int c2 = 0; c2 < CPW; ++c2) a[c2] = Ys[buf][(st * 4 + q) * LDY + (wave_c * CPW + c2) * 16 + lr];
-#pragma unroll
-            for (int kt = 0; kt < KPW; ++kt) b[kt] = Xs[buf][(st * 4 + q) * LDX + (wave_k * KPW + kt) * 16 + lr];
+            if (st + 1 < MC / 4) read_frags(st + 1, (st + 1) & 1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int c2 = 0; c2 < CPW; ++c2)
 #pragma unroll
                 for (int kt = 0; kt < KPW; ++kt)
-                    acc[c2][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c2], b[kt], acc[c2][kt], 0, 0, 0);
+                    acc[c2][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1][c2], b[st & 1][kt], acc[c2][kt], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
@@ -919,7 +935,7 @@ int wgrad_slices(const ConvGeom& g) {
     const int bki = wgrad_bki(M, N, K);
     const int lds_bytes = 2 * 32 * ((bki + 16) + (bco == 16 ? 16 : bco + 16)) * 4;
     const int resident = std::max(32, (int)(par_scale() * 256 * std::max(1, std::min(8, (160 * 1024) / lds_bytes))));
-    if ((long)tiles * S < 4l * resident) S = fill_waves(tiles, S, resident);
+    if ((long)tiles * S < 4l * resident) S = fill_waves(tiles, S, resident, 0.95);
     const int maxS = std::max(1, M / 256);
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
