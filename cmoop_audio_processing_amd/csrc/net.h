@@ -51,6 +51,12 @@ void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGe
                         float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws = nullptr,
                         size_t sk_floats = 0, int mode = GEMM_DEFAULT);
 
+// cached device allocations (net.hip): get may return stale contents, free never blocks on other streams
+void* pool_alloc(size_t bytes);
+void pool_free(void* p);
+void* pool_alloc_pinned(size_t bytes);
+void pool_free_pinned(void* p);
+
 struct Act {
     float* data = nullptr;
     float* grad = nullptr;

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <numeric>
 #include <thread>
 
@@ -82,9 +83,90 @@ ProfileTotals& profile_totals() {
 }
 
 // ---------------------------------------------------------------------------
+// Device-memory cache shared by the candidates of a process.  hipFree waits for the work already queued on EVERY
+// stream of the device, so tearing a candidate down buffer by buffer (~100 buffers) stalls its worker while the other
+// streams' queues drain; candidates of one search reuse a handful of buffer sizes, so finished candidates hand their
+// buffers to the next one instead.  Buffers are handed out with stale contents (as hipMalloc may): every consumer
+// writes before it reads.  CMOOP_POOL_GB caps the cached bytes (default 96; 0 disables the cache).
+namespace {
+class DevicePool {
+  public:
+    explicit DevicePool(bool host) : host_(host) {}
+    void* get(size_t bytes) {
+        const size_t want = round_up(bytes);
+        int dev = 0;
+        CMOOP_HIP(hipGetDevice(&dev));
+        if (cap_bytes() > 0) {
+            std::lock_guard<std::mutex> l(mu_);
+            auto& fl = free_[dev];
+            auto it = fl.lower_bound(want);
+            if (it != fl.end() && it->first <= want + want / 8) {
+                void* p = it->second;
+                cached_ -= it->first;
+                sizes_[p] = it->first;
+                fl.erase(it);
+                return p;
+            }
+        }
+        void* p = nullptr;
+        if (host_) CMOOP_HIP(hipHostMalloc(&p, want));
+        else CMOOP_HIP(hipMalloc(&p, want));
+        std::lock_guard<std::mutex> l(mu_);
+        sizes_[p] = want;
+        return p;
+    }
+    void put(void* p) {
+        if (!p) return;
+        size_t bytes = 0;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            auto it = sizes_.find(p);
+            if (it != sizes_.end()) { bytes = it->second; sizes_.erase(it); }
+            if (bytes && cached_ + bytes <= cap_bytes()) {
+                free_[dev].emplace(bytes, p);
+                cached_ += bytes;
+                return;
+            }
+        }
+        if (host_) hipHostFree(p);
+        else hipFree(p);
+    }
+  private:
+    static size_t round_up(size_t b) {
+        const size_t g = b <= (1u << 20) ? 4096 : (256u << 10);
+        return std::max<size_t>((b + g - 1) / g * g, g);
+    }
+    static size_t cap_bytes() {
+        static const size_t v = [] {
+            const char* e = std::getenv("CMOOP_POOL_GB");
+            const double gb = e ? std::atof(e) : 96.0;
+            return gb > 0 ? (size_t)(gb * (double)(1ull << 30)) : (size_t)0;
+        }();
+        return v;
+    }
+    const bool host_;
+    std::mutex mu_;
+    std::map<int, std::multimap<size_t, void*>> free_;
+    std::map<void*, size_t> sizes_;
+    size_t cached_ = 0;
+};
+DevicePool& pool(bool host) {
+    // leaked on purpose: worker threads may outlive static destructors
+    static DevicePool* dev = new DevicePool(false);
+    static DevicePool* pinned = new DevicePool(true);
+    return host ? *pinned : *dev;
+}
+}  // namespace
+
+void* pool_alloc(size_t bytes) { return pool(false).get(bytes); }
+void pool_free(void* p) { pool(false).put(p); }
+void* pool_alloc_pinned(size_t bytes) { return pool(true).get(bytes); }
+void pool_free_pinned(void* p) { pool(true).put(p); }
+
 float* Net::dalloc(size_t floats) {
-    void* p = nullptr;
-    CMOOP_HIP(hipMalloc(&p, std::max<size_t>(floats, 4) * sizeof(float)));
+    void* p = pool_alloc(std::max<size_t>(floats, 4) * sizeof(float));
     allocs_.push_back(p);
     return static_cast<float*>(p);
 }
@@ -102,7 +184,8 @@ Net::Net(const int32_t gene[6], const NetConfig& cfg, int T, int F, uint32_t see
 
 Net::~Net() {
     for (auto& e : ev_pool_) { hipEventDestroy(e.t.start); hipEventDestroy(e.t.stop); }
-    for (void* p : allocs_) hipFree(p);
+    hipStreamSynchronize(stream_);            // nothing of this candidate may still be running when its buffers are reused
+    for (void* p : allocs_) pool_free(p);
 }
 
 void Net::build_plan() {
@@ -251,8 +334,7 @@ void Net::build_plan() {
     for (auto& op : ops_) {
         if (op.kind == OP_BN) op.bn_buf = dalloc(4 * (size_t)op.Cout);
         if (op.kind == OP_POOL) {
-            void* p = nullptr;
-            CMOOP_HIP(hipMalloc(&p, (size_t)Bmax_ * acts_[op.out].per_sample()));
+            void* p = pool_alloc((size_t)Bmax_ * acts_[op.out].per_sample());
             allocs_.push_back(p);
             op.arg = static_cast<uint8_t*>(p);
         }
@@ -636,11 +718,11 @@ EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Data
     int32_t* d_idx = nullptr;
     int32_t* d_preds = nullptr;
     int64_t* d_cm = nullptr;
-    CMOOP_HIP(hipHostMalloc(&h_idx, ds.n_train * 4));
-    CMOOP_HIP(hipMalloc(&d_idx, ds.n_train * 4));
-    CMOOP_HIP(hipMalloc(&d_preds, ds.n_val * 4));
-    CMOOP_HIP(hipMalloc(&d_cm, (size_t)cfg.classes * cfg.classes * 8));
-    auto cleanup = [&]() { hipHostFree(h_idx); hipFree(d_idx); hipFree(d_preds); hipFree(d_cm); };
+    h_idx = static_cast<int32_t*>(pool_alloc_pinned(ds.n_train * 4));
+    d_idx = static_cast<int32_t*>(pool_alloc(ds.n_train * 4));
+    d_preds = static_cast<int32_t*>(pool_alloc(ds.n_val * 4));
+    d_cm = static_cast<int64_t*>(pool_alloc((size_t)cfg.classes * cfg.classes * 8));
+    auto cleanup = [&]() { hipStreamSynchronize(stream); pool_free_pinned(h_idx); pool_free(d_idx); pool_free(d_preds); pool_free(d_cm); };
     try {
         // Model.fit + EarlyStopping(monitor='val_loss', patience) -- keras/src/callbacks/early_stopping.py (3.6)
         double best = INFINITY, last_val_acc = 0.0, last_val_loss = 0.0;
