@@ -124,10 +124,6 @@ class Net : public GemmHook {
     int T_, F_, Bmax_;
     uint32_t seed_;
     hipStream_t stream_;
-    // weight gradients are off the backward critical path (only Adam needs them): they run on a low-priority side
-    // stream, forked per layer once dY is final and joined before the optimiser step (CMOOP_SIDE_STREAM=0 disables)
-    hipStream_t side_ = nullptr;
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     std::vector<Act> acts_;
     std::vector<Op> ops_;
     std::vector<void*> allocs_;

@@ -180,20 +180,11 @@ Net::Net(const int32_t gene[6], const NetConfig& cfg, int T, int F, uint32_t see
     std::memcpy(gene_, gene, sizeof(gene_));
     Bmax_ = std::max(cfg.batch, cfg.eval_batch);
     build_plan();
-    const char* ss = std::getenv("CMOOP_SIDE_STREAM");
-    if (!(ss && ss[0] == '0')) {
-        int least = 0, greatest = 0;
-        CMOOP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        CMOOP_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, least));
-        CMOOP_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        CMOOP_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    }
 }
 
 Net::~Net() {
     for (auto& e : ev_pool_) { hipEventDestroy(e.t.start); hipEventDestroy(e.t.stop); }
     hipStreamSynchronize(stream_);            // nothing of this candidate may still be running when its buffers are reused
-    if (side_) { hipStreamSynchronize(side_); hipStreamDestroy(side_); hipEventDestroy(ev_fork_); hipEventDestroy(ev_join_); }
     for (void* p : allocs_) pool_free(p);
 }
 
@@ -603,13 +594,10 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B) {
             const ConvGeom g = geom_of(op, B);
             const float* dY = acts_[op.out].grad;
             Act& ia = acts_[op.in];
-            hipStream_t ws = stream_;
-            if (side_) {   // dY is final once everything launched so far on the main stream has run
-                CMOOP_HIP(hipEventRecord(ev_fork_, stream_));
-                CMOOP_HIP(hipStreamWaitEvent(side_, ev_fork_, 0));
-                ws = side_;
-            }
-            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, red_ws_, ws, this, op.gemm_mode);
+            // (measured, not adopted: wgrad on a low-priority side stream forked per layer and joined before Adam -- off the
+            // dgrad critical path -- ran 35 % SLOWER, 65 vs 100 TFLOP/s whole-job: the cross-stream event waits cost more
+            // than the overlap wins)
+            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, red_ws_, stream_, this, op.gemm_mode);
             if (op.need_dgrad)
                 conv_backward_data(dY, params_ + op.w_off, ia.grad, g, wd_ws_, op.in_is_relu ? ia.data : nullptr,
                                    op.in_mask_scale, op.dgrad_accumulate, stream_, this, splitk_ws_, splitk_ws_floats_, op.gemm_mode);
@@ -640,15 +628,9 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B) {
             break;
         }
         case OP_CONV1: {
-            hipStream_t ws = stream_;
-            if (side_) {
-                CMOOP_HIP(hipEventRecord(ev_fork_, stream_));
-                CMOOP_HIP(hipStreamWaitEvent(side_, ev_fork_, 0));
-                ws = side_;
-            }
-            launch_conv1_wgrad(X, idx, row0, acts_[op.out].grad, wgrad_ws_, B, T_, F_, op.Cout, op.KS, ws);
+            launch_conv1_wgrad(X, idx, row0, acts_[op.out].grad, wgrad_ws_, B, T_, F_, op.Cout, op.KS, stream_);
             launch_reduce_slices(wgrad_ws_, grads_ + op.w_off, conv1_wgrad_blocks(B, T_, F_),
-                                 (int64_t)op.Cout * (op.KS * op.KS + 1), ws);
+                                 (int64_t)op.Cout * (op.KS * op.KS + 1), stream_);
             break;
         }
         }
@@ -661,10 +643,6 @@ void Net::train_step(const float* X, const int32_t* y, const int32_t* idx, int64
     forward(X, idx, row0, B, true);
     launch_softmax_ce(acts_[logits_].data, y, idx, row0, B, cfg_.classes, acts_[logits_].grad, acc_train_, nullptr, stream_);
     backward(X, idx, row0, B);
-    if (side_) {   // join: the optimiser (and the next forward, which overwrites the activations wgrad reads) waits for every wgrad
-        CMOOP_HIP(hipEventRecord(ev_join_, side_));
-        CMOOP_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
-    }
     ++iterations_;
     const double t = (double)iterations_;
     const double b1 = cfg_.beta1, b2 = cfg_.beta2;
