@@ -63,7 +63,7 @@ void cmoop_config_default(cmoop_config* c) {
     std::memset(c, 0, sizeof(*c));
     c->variant = CMOOP_VARIANT_A; c->classes = 10; c->epochs = 300; c->batch = 64; c->patience = 5;
     c->early_stop = 1; c->restore_best = 0; c->acc_readout = 0; c->fpr_variant = CMOOP_FPR_V1; c->shuffle = 1;
-    c->eval_batch = 256; c->n_slots = 16; c->profile_every = 0;
+    c->eval_batch = 256; c->n_slots = 8; c->profile_every = 0;
     c->lr = 1e-3; c->beta1 = 0.9; c->beta2 = 0.999; c->adam_eps = 1e-7; c->bn_eps = 1e-3; c->bn_momentum = 0.99;
     c->dropout = 0.3;
 }

@@ -15,7 +15,7 @@ namespace cmoop {
 struct NetConfig {
     int variant = 0, classes = 10, epochs = 300, batch = 64, patience = 5;
     int early_stop = 1, restore_best = 0, acc_readout = 0, fpr_variant = 0, shuffle = 1;
-    int eval_batch = 256, n_slots = 16, profile_every = 0;
+    int eval_batch = 256, n_slots = 8, profile_every = 0;
     int gemm_mode = GEMM_FP32;   // resolved GemmMode of the MFMA layers (never GEMM_DEFAULT here)
     double lr = 1e-3, beta1 = 0.9, beta2 = 0.999, adam_eps = 1e-7, bn_eps = 1e-3, bn_momentum = 0.99, dropout = 0.3;
 };

@@ -55,7 +55,7 @@ class EvalConfig:
     max_model_size: float = 2.5   # MAX_MODEL_SIZE
     max_fpr: float = 0.1          # MAX_FPR
     seed: int = 0                 # the reference seeds nothing; the build makes runs reproducible
-    n_slots: int = 16             # candidates in flight per GPU (each on its own HIP stream; 16 measured +6 % over 8)
+    n_slots: int = 8              # candidates in flight per GPU (each on its own HIP stream; 6-16 measure the same)
     eval_batch: int = 256
     profile_every: int = 0
     compute: str = "fp32"       # GEMM_CODES: arithmetic of the conv/dense MFMA kernels

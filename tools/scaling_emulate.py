@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--clips", type=int, default=30000)
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--classes", type=int, default=10)
-    ap.add_argument("--slots", type=int, default=16)
+    ap.add_argument("--slots", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--worlds", default="1,2,4,8")
     args = ap.parse_args()
