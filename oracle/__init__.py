@@ -37,4 +37,6 @@ Pinning status
   reference altogether; librosa==0.11.0 is pinned in requirements.txt:80 but
   has no call site, so the oracle restates librosa's published mel-spectrogram
   algorithm).  For these the oracle is the definition the HIP path is held to.
+* NO REFERENCE COUNTERPART: ``OracleConfig.compute = "bf16"`` (oracle/net.py) restates the build's own opt-in
+  bf16-train mode (BASELINE.json configs[4]); the reference trains in fp32 only.
 """
