@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     constexpr int LDX = BKI + 16;                          // == 16 mod 32
     constexpr int LDY = (BCO == 16) ? 16 : BCO + 16;
     constexpr int CT = BCO / 16, KT = BKI / 16;             // co tiles, k tiles of the block
-    constexpr int WC = CT >= 8 ? 2 : (CT >= 4 ? 4 : CT);    // waves along co; 4 / WC along k
+    constexpr int WC = CT >= 4 ? 2 : CT;                    // waves along co; 4 / WC along k (2x2 waves for 64- and 128-wide co tiles)
     constexpr int WK = 4 / WC;
     constexpr int CPW = CT / WC, KPW = KT / WK;             // co tiles / k tiles per wave
     constexpr int TPRX = BKI / 4, RPPX = 256 / TPRX, XPASS = MC / RPPX;
