@@ -607,6 +607,10 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
 // The MFMA reduction index is the pixel row m; both operands are read from LDS
 // m-major (ds_read_b32, leading dimension == 16 mod 32 -> conflict-free).
 // grid = (K tiles of 64, N tiles of BCO, S row-slices); partials P[S][N][K].
+// (Measured alternative, not adopted: an XCD-aware 1-D grid that keeps all K tiles of a (co tile, slice) group on one
+// XCD cuts the fabric-side reads of the 128->128 k5 launch from 559 MB to 84 MB -- 67 MB algorithmic -- but per-XCD wave
+// quantisation (25 K tiles per group on 64 slots) makes it 4-10 % slower alone and 0.6 % slower whole-job: the re-reads
+// are served by L2 / Infinity Cache and the kernel is MFMA-bound.)
 // (Measured alternative, not adopted: transposing 4x4 blocks in registers on the way into LDS so that fragments are
 // ds_read_b128 as in the forward kernel -- conflict-free with pitch 40 + XOR swizzle, coalesced gathers -- ran 8 %
 // slower than this m-major image with ds_read_b32 fragments: 95 vs 103 TFLOP/s on 128->128 k5.)
