@@ -239,6 +239,9 @@ def main():
         tot_fl = sum(e["flops"] for e in entries)
         roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "traffic_note": "PMC needs its own rocprofv3 passes (one counter each), so it is not collected in this run: "
+                                    "profiles/r01_pmc_fetch_write_final_kernels.csv holds FETCH_SIZE / WRITE_SIZE of this kernel on its "
+                                    "heaviest layer shape (175 MB per launch against 68 MB algorithmic; compute-bound)",
                     "kernel": dom["kernel"], "sampled_launches": dom["launches"],
                     "timing": "hipEventRecord pairs (under rocprofv3)" if under_rocprof else "hipExtLaunchKernelGGL start/stop events",
                     "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5),
