@@ -106,3 +106,16 @@ def test_product_package_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_compute_mode_reaches_the_abi_struct():
+    """EvalConfig.compute -> cmoop_config.gemm_mode (include/cmoop.h CMOOP_GEMM_*); the default is the reference's fp32."""
+    import pytest
+    from cmoop_audio_processing_amd import EvalConfig
+    assert EvalConfig().compute == "fp32" and EvalConfig().to_struct().gemm_mode == 0
+    assert EvalConfig(compute="bf16x3").to_struct().gemm_mode == 2
+    assert EvalConfig(compute="bf16").to_struct().gemm_mode == 3
+    with pytest.raises(KeyError):
+        EvalConfig(compute="fp16").to_struct()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cmoop.h")).read()
+    assert "#define CMOOP_GEMM_BF16X3 2" in hdr and "#define CMOOP_GEMM_BF16 3" in hdr and "int32_t gemm_mode;" in hdr
