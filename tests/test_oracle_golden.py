@@ -150,3 +150,24 @@ def test_bf16_oracle_is_sensitive_to_fp32_summation_order():
         pytest.skip("this torch build runs the same conv algorithm with and without mkldnn")
     assert e32 < 1e-4
     assert e16 > 20 * e32 and e16 > 1e-4
+
+
+def test_bf16_oracle_conv_follows_its_stated_definition():
+    """OracleConfig.compute='bf16' (the build's own mode, no reference counterpart): y = conv(q(x), q(w)) + b,
+    dx = dgrad(q(dy), q(w)), dw = wgrad(q(x), q(dy)), db = sum(dy), q = round-to-nearest-even to bf16."""
+    import torch
+    from oracle import net as ON
+    rs = np.random.RandomState(1)
+    x = torch.from_numpy(rs.randn(2, 16, 9, 7).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((rs.randn(8, 3, 3, 16) / 12).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rs.randn(8).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rs.randn(2, 8, 9, 7).astype(np.float32))
+    q = ON.bf16_round
+    assert torch.equal(q(torch.tensor([1.0 + 2.0 ** -9, 1.0 + 3 * 2.0 ** -9])), torch.tensor([1.0, 1.0 + 2.0 ** -7]))   # ties to even
+    y = ON._Bf16Conv.apply(x, w, b, 1)
+    assert torch.equal(y, ON.conv_same(q(x), q(w), b, 1))
+    y.backward(dy)
+    xq, wq = q(x.detach()).requires_grad_(True), q(w.detach()).requires_grad_(True)
+    ON.conv_same(xq, wq, None, 1).backward(q(dy))
+    assert torch.equal(x.grad, xq.grad) and torch.equal(w.grad, wq.grad)
+    assert torch.allclose(b.grad, dy.sum(dim=(0, 2, 3)))
