@@ -4,20 +4,37 @@
 One "step" = one pass of the hot path over one generation:
 ``compute_objectives_and_constraints(population)`` for pop=40 candidates
 (BASELINE.json configs[1]: "pop=40 gen=1 fitness eval on 1xMI355X: HIP MFCC +
-tiny-CNN train, GSC 10-keyword"; reference call site nsga_penalty.py:613/670).
-Inputs are synthetic 1 s @ 16 kHz clips, turned into
-standardised [N,101,40] log-mel features by the HIP front end BEFORE the timed
-region, so the timed region starts with features resident in HBM.  Every
-candidate trains for a fixed epoch budget (early stopping off) so CPU and GPU do
-identical algorithmic work, then runs the inference/confusion readout.
+tiny-CNN train, GSC 10-keyword"; reference call site nsga_penalty.py:613/670,
+the loop itself :418-442).  Inputs are synthetic 1 s @ 16 kHz clips (SURVEY.md
+§8d), turned into standardised [N,101,40] log-mel features by the HIP front end
+BEFORE the timed region, so the timed region starts with features resident in
+HBM.  Every candidate trains for a fixed epoch budget (early stopping off) so
+CPU and GPU do identical algorithmic work, then runs the inference/confusion
+readout.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: every rank holds the same seeded population, evaluates its LPT shard and
-the objective vectors are exchanged with one RCCL all_gather per step.  The
-population is fixed at --pop (strong scaling: the reference shards ONE
-generation); --weak multiplies it by N.
+Wall-clock budget.  One generation of the headline workload (pop 40, N=30 000,
+101x40, fp32) takes about a minute on one MI355X, so K and W are UPPER BOUNDS
+under ``--budget-s`` (seconds from process start by which the JSON line must be
+out; default 450 for the driver's 600 s limit):
+* warm-up = up to W light untimed passes: the whole population for one epoch on
+  a few hundred clips -- loads every kernel family and fills the buffer cache;
+* the timed region holds as many WHOLE generations as fit (>= 1, <= K): the
+  first one is timed, then ``plan_steps`` decides how many more fit.  The line
+  reports ``steps`` = generations actually timed and ``steps_requested`` = K;
+* the CPU-baseline leg runs before the timed region on a bounded sample
+  (``--cpu-baseline-s``) and the isolated-kernel leg is a few launches, so
+  ``roofline`` and ``cpu_baseline`` are always in the line.
+
+N > 1: ``--gpus N`` without a torchrun environment starts the N ranks itself
+(child ``python -m torch.distributed.run``, before any GPU call in the parent)
+and relays rank 0's JSON line.  Every rank holds the same seeded population;
+the candidates are drained from ONE longest-first queue (``--schedule
+dynamic``) or LPT buckets (``static``) and the objective vectors are exchanged
+with one RCCL all_gather per step.  The population is fixed at --pop (strong
+scaling: the reference shards ONE generation); --weak multiplies it by N.
 
 Rank 0 prints ONE JSON line (contract in the task statement), including
 ``roofline`` (HIP-event timings of the dominant MFMA kernel sampled inside the
@@ -29,10 +46,15 @@ import ctypes as C
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
+import threading
 import time
 
-import numpy as np
+T_PROCESS_START = time.perf_counter()
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -41,17 +63,31 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 
 # opt-in modes: the bf16 MFMA runs at 16x the fp32 MFMA rate (same guide); bf16x3 spends six bf16 MFMAs per product
 PEAK_BY_MODE = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": round(16 * PEAK_FP32_MFMA_TFLOPS / 6, 1), "bf16": 16 * PEAK_FP32_MFMA_TFLOPS}
 
+#: PMC traffic of the dominant kernel instantiations on their heaviest layer shape, from the committed separate
+#: `rocprofv3 --pmc` passes (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); bench.py cannot collect
+#: counters itself (they need their own profiler passes), so the line cites the file the numbers come from.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic_per_kernel.json")
 
-def synth_waveforms(n, classes, seed, device, n_samples=16000, chunk=2000):
+
+def synth_waveforms(n, classes, seed, device, n_samples=16000, chunk=2000, hard=False):
     """per class 3 sinusoids log-spaced in 200-4000 Hz with random phase, amplitude
-    U(0.1,1), plus N(0,1)-shaped noise at 0 dB SNR.  Seeded torch generator (Philox on GPU)."""
+    U(0.1,1), plus N(0,1)-shaped noise at 0 dB SNR.  Seeded torch generator (Philox on GPU).
+
+    hard=True (hypervolume runs only, never the throughput metric): -10 dB SNR and neighbouring classes share two
+    of their three partials, so accuracies spread over roughly 0.6-0.95 like the reference's published Pareto range
+    (0.88-0.931) instead of saturating at 1.0."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     y = (torch.arange(n, device=device) % classes).to(torch.int32)
     perm = torch.randperm(n, generator=g, device=device)
     y = y[perm].contiguous()
-    freqs = torch.logspace(np.log10(200.0), np.log10(4000.0), classes * 3, device=device).reshape(classes, 3)
+    if hard:
+        base = torch.logspace(np.log10(200.0), np.log10(4000.0), classes + 2, device=device)
+        freqs = torch.stack([base[c:c + 3] for c in range(classes)])            # class c and c+1 share two partials
+    else:
+        freqs = torch.logspace(np.log10(200.0), np.log10(4000.0), classes * 3, device=device).reshape(classes, 3)
+    noise_gain = float(10.0 ** (10.0 / 20.0)) if hard else 1.0                 # -10 dB SNR vs 0 dB
     t = torch.arange(n_samples, device=device, dtype=torch.float32) / 16000.0
     wav = torch.empty((n, n_samples), dtype=torch.float32, device=device)
     for s in range(0, n, chunk):
@@ -60,16 +96,17 @@ def synth_waveforms(n, classes, seed, device, n_samples=16000, chunk=2000):
         ph = torch.rand((len(yy), 3), generator=g, device=device) * (2 * np.pi)
         sig = torch.sin(2 * np.pi * f[:, :, None] * t[None, None, :] + ph[:, :, None]).sum(1)
         sig = sig / sig.pow(2).mean(dim=1, keepdim=True).sqrt()
-        noise = torch.randn((len(yy), n_samples), generator=g, device=device)
+        noise = torch.randn((len(yy), n_samples), generator=g, device=device) * noise_gain
         amp = 0.1 + 0.9 * torch.rand((len(yy), 1), generator=g, device=device)
         wav[s:s + chunk] = amp * (sig + noise) * 0.5
     return wav, y
 
 
-def cpu_baseline(pop, variant, classes, T, F, n_train, n_val, epochs, X_sample, y_sample, budget_s=25.0):
+def cpu_baseline(pop, variant, classes, T, F, n_train, n_val, epochs, X_sample, y_sample, budget_s=15.0):
     """Time the oracle (torch-CPU restatement of the reference path) on this box's host cores
     on a bounded sample: train steps of batch 64 + inference on 64 rows for the cheapest,
-    median and most expensive candidate of the population; extrapolate by closed-form FLOPs."""
+    median and most expensive candidate of the population; extrapolate by closed-form FLOPs.
+    Bounded by ``budget_s`` of wall-clock (a third per candidate; at least one train step each)."""
     import torch
     from cmoop_audio_processing_amd import genes as G
     from oracle import net as ON
@@ -79,24 +116,29 @@ def cpu_baseline(pop, variant, classes, T, F, n_train, n_val, epochs, X_sample, 
     picks = [int(order[0]), int(order[len(order) // 2]), int(order[-1])]
     cfg = ON.OracleConfig(variant=variant, classes=classes, batch=64)
     done_flops, spent, sample = 0.0, 0.0, []
-    for i in picks:
+    t_leg = time.perf_counter()
+    for n_pick, i in enumerate(picks):
+        left = budget_s - (time.perf_counter() - t_leg)
+        share = max(left / (len(picks) - n_pick), 0.0)
         net = ON.OracleNet(pop[i], cfg, 1)
         xb, yb = X_sample[:64], y_sample[:64]
-        net.train_step(xb, yb)                      # warm-up (allocator, MKLDNN primitives)
-        steps = 0
-        t0 = time.perf_counter()
-        while True:
+        tw = time.perf_counter()
+        net.train_step(xb, yb)                      # warm-up (allocator, MKLDNN primitives); counted if it is all we can afford
+        t_warm = time.perf_counter() - tw
+        steps, t0 = 0, time.perf_counter()
+        while steps < 6 and (time.perf_counter() - t0) + 1.5 * t_warm < share * 0.8:
             net.train_step(xb, yb)
             steps += 1
-            el = time.perf_counter() - t0
-            if el > budget_s / 4 or steps >= 6:
-                break
+        if steps == 0:                              # budget too small for a second step: use the warm-up step itself
+            steps, t_train = 1, t_warm
+        else:
+            t_train = time.perf_counter() - t0
         t1 = time.perf_counter()
         net.evaluate(xb, yb)
-        t2 = time.perf_counter()
+        t_eval = time.perf_counter() - t1
         done_flops += fl[i] * 64 * (3 * steps + 1)
-        spent += (t2 - t0)
-        sample.append(f"gene{tuple(pop[i])}:{steps} train steps+1 eval batch in {t2 - t0:.1f}s")
+        spent += t_train + t_eval
+        sample.append(f"gene{tuple(pop[i])}:{steps} train steps+1 eval batch in {t_train + t_eval:.1f}s")
     rate = done_flops / spent                                        # algorithmic FLOP/s the oracle sustains
     per_eval = np.array(fl, dtype=np.float64) * (3 * n_train * epochs + n_val * epochs + n_val)
     hours = per_eval.sum() / rate / 3600.0
@@ -105,11 +147,95 @@ def cpu_baseline(pop, variant, classes, T, F, n_train, n_val, epochs, X_sample, 
                       f"N_train={n_train}, E={epochs} ({rate / 1e9:.0f} GFLOP/s sustained)"}
 
 
-def main():
+def plan_steps(first_step_s, now_s, deadline_s, steps_requested, safety=1.05):
+    """How many whole generations the timed region holds in total (>= 1, <= steps_requested), given that the first
+    took ``first_step_s`` and ended at ``now_s``; later ones are assumed to take ``safety`` x as long and must
+    finish by ``deadline_s`` (all on one clock)."""
+    if steps_requested <= 1:
+        return 1
+    per = max(first_step_s * safety, 1e-9)
+    more = int(max(0.0, deadline_s - now_s) // per)
+    return 1 + max(0, min(steps_requested - 1, more))
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """--gpus N without a torchrun environment: start the N ranks as a CHILD process tree (never an exec of this
+    process, and before anything here has touched the GPU), relay rank 0's JSON line, exit with the child's code."""
+    import torch
+    if not (args.same_device or args.stub):
+        have = torch.cuda.device_count()            # counting devices does not initialise the GPU
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CMOOP_BENCH_T0_OFFSET=str(time.perf_counter() - T_PROCESS_START))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in r.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+    if line is not None:
+        print(line, flush=True)
+    elif r.stdout:
+        sys.stderr.write(r.stdout[-4000:])
+    if r.returncode == 0 and line is None:
+        print("bench.py: the ranks exited 0 but printed no JSON line", file=sys.stderr)
+        return 3
+    return r.returncode
+
+
+class StubEvaluator:
+    """CPU rehearsal of the HARNESS logic only (tests; ``--stub``): no GPU, no kernels, no oracle.  A candidate
+    'costs' --stub-ms-per-gflop of sleep per closed-form forward GFLOP/sample; results are placeholders.  Lines
+    produced with it carry "data": "stub" and are never a measurement."""
+
+    def __init__(self, cfg, variant, classes, T, F, ms_per_gflop):
+        from cmoop_audio_processing_amd import evaluator as E
+        self.E, self.config, self.variant, self.classes, self.T, self.F = E, cfg, variant, classes, T, F
+        self.ms_per_gflop = ms_per_gflop
+        self.evals_done, self._gen = 0, 0
+        self.last_rank_of = []
+        E._queue_serial[0] += 1
+        self._prefix = f"cmoop/stubqueue/{E._queue_serial[0]}"
+
+    def compute_objectives_and_constraints(self, population):
+        from cmoop_audio_processing_amd import genes as G
+        gl = [G.normalize_hparams(hp) for hp in population]
+        costs = [G.fwd_flops_per_sample(g, self.variant, self.classes, self.T, self.F) / 1e9 for g in gl]
+        self._gen += 1
+        dist = self.E._dist()
+        rank = float(dist.get_rank()) if dist is not None else 0.0
+
+        def one(i):
+            time.sleep(costs[i] * self.ms_per_gflop * 1e-3)
+            return [0.5, G.model_size_mb(gl[i], self.variant, self.classes), 0.05, rank]
+
+        def local(pull):
+            return {i: one(i) for i in iter(pull, -1)}
+        res = self.E.queued_map(local, costs, 4, f"{self._prefix}/{self._gen}")
+        self.evals_done += len(gl)
+        self.last_rank_of = [int(r) for r in res[:, 3]]
+        return [{"hparams": hp, "objs": [-r[0], r[1], r[2]], "CV": 0.0} for hp, r in zip(population, res)]
+
+
+def main(argv=None, t_origin=None):
+    """t_origin: perf_counter value the budget clock starts at (default: this process' start; tests pass 'now')."""
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=2, help="upper bound on timed generations (whole generations that fit --budget-s)")
+    ap.add_argument("--warmup", type=int, default=1, help="upper bound on light untimed warm-up passes (each: the population, 1 epoch, a few hundred clips)")
+    ap.add_argument("--budget-s", type=float, default=450.0,
+                    help="seconds from process start by which the JSON line must be printed (driver limit 600 s)")
+    ap.add_argument("--cpu-baseline-s", type=float, default=15.0, help="wall-clock cap of the CPU-baseline leg")
     ap.add_argument("--pop", type=int, default=40)
     ap.add_argument("--clips", type=int, default=30000, help="synthetic clips (80/10/10 split)")
     ap.add_argument("--epochs", type=int, default=2, help="fixed epoch budget per candidate; 10 = full SURVEY §8d protocol")
@@ -118,6 +244,8 @@ def main():
     ap.add_argument("--slots", type=int, default=8, help="candidates in flight per GPU (6-16 measure the same; 4 is 9 % slower)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--weak", action="store_true", help="population = pop * gpus")
+    ap.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"],
+                    help="N>1 candidate placement: one shared longest-first queue (c10d store counter) or LPT buckets by FLOPs")
     ap.add_argument("--profile-every", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-mode", default="fp32", choices=["fp32", "bf16x3", "bf16"],
@@ -126,7 +254,21 @@ def main():
                          "not bit-exact); bf16 = operands rounded to bf16, fp32 accumulation (BASELINE configs[4] 'bf16 train')")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --same-device rehearses N ranks on one GPU")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (single-GPU rehearsal of the N>1 path)")
-    args = ap.parse_args()
+    ap.add_argument("--stub", action="store_true", help="harness rehearsal without a GPU (tests only): StubEvaluator, gloo; never a measurement")
+    ap.add_argument("--stub-ms-per-gflop", type=float, default=2.0)
+    args = ap.parse_args(argv)
+    if args.stub:
+        args.backend = "gloo"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+
+    # the clock the budget runs on starts with the (parent) process: torchrun children inherit the parent's offset
+    if t_origin is None:
+        t_origin = T_PROCESS_START - float(os.environ.get("CMOOP_BENCH_T0_OFFSET", "0") or 0.0)
+
+    def since_start():
+        return time.perf_counter() - t_origin
 
     # under rocprofv3 the tool library crashes on hipExtLaunchKernelGGL (ROCm 7.2): fall back to plain
     # hipEventRecord pairs around the sampled launches there (slightly inflated when streams overlap)
@@ -135,178 +277,255 @@ def main():
         os.environ["CMOOP_PROFILE_PAIRS"] = "1"
     if args.gemm_mode != "fp32":
         os.environ["CMOOP_GEMM_MODE"] = args.gemm_mode      # read once by the library
-
-    global PEAK_FP32_MFMA_TFLOPS
-    PEAK_FP32_MFMA_TFLOPS = PEAK_BY_MODE[args.gemm_mode]   # the roofline of the arithmetic actually used
+    peak = PEAK_BY_MODE[args.gemm_mode]                      # the roofline of the arithmetic actually used
 
     import torch
     import torch.distributed as dist
-    from cmoop_audio_processing_amd import EvalConfig, PopulationEvaluator, _lib, frontend, genes as G
+    from cmoop_audio_processing_amd import EvalConfig, genes as G
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to mislabel the run", file=sys.stderr)
+        return 2
     if args.same_device:
         local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        if not args.stub:
+            torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
-    else:
+    elif not args.stub:
         torch.cuda.set_device(0)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cpu") if args.stub else torch.device("cuda", local_rank if world > 1 else 0)
+    coll_dev = dev if (world > 1 and args.backend == "nccl") else torch.device("cpu")
     variant = G.VARIANT_NAMES[args.variant]
 
-    # ---- untimed setup: synthetic clips -> HIP front end -> StandardScaler (nsga_penalty quirk Q1: refit per split)
-    wav, y = synth_waveforms(args.clips, args.classes, 1234, dev)
-    frontend.log_mel(wav[:64])                       # warm-up (code object load, tables)
-    torch.cuda.synchronize()
-    t_fe = time.perf_counter()
-    feats = frontend.log_mel(wav)                    # synchronous: returns after the kernel finished
-    t_fe = time.perf_counter() - t_fe
-    fe_bytes = wav.numel() * 4 + feats.numel() * 4   # algorithmic HBM bytes: clips in + log-mel out
-    frontend_info = {"clips": int(args.clips), "ms": round(t_fe * 1e3, 3), "clips_per_s": round(args.clips / t_fe),
-                     "algorithmic_GBps": round(fe_bytes / t_fe / 1e9, 1), "hbm_peak_GBps": 8000,
-                     "frac_of_hbm_peak": round(fe_bytes / t_fe / 8e12, 4)}
-    del wav
-    n_tr, n_va = int(args.clips * 0.8), int(args.clips * 0.1)
-    Xtr, ytr = feats[:n_tr].contiguous(), y[:n_tr].contiguous()
-    Xva, yva = feats[n_tr:n_tr + n_va].contiguous(), y[n_tr:n_tr + n_va].contiguous()
-    del feats
-    frontend.prepare_dataset(Xtr, Xva, None, mode="refit")
-    T, F = int(Xtr.shape[1]), int(Xtr.shape[2])
+    # heartbeat on stderr (stdout carries only the JSON line): long steps must not look hung
+    stop_hb = threading.Event()
+    phase = {"name": "setup"}
 
-    cfg = EvalConfig.preset("nsga_penalty", variant=args.variant, classes=args.classes, epochs=args.epochs,
-                            early_stop=False, seed=args.seed, n_slots=args.slots, profile_every=args.profile_every)
-    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+    def heartbeat():
+        while not stop_hb.wait(60.0):
+            print(f"[bench rank {rank}] {phase['name']}, {since_start():.0f} s since start", file=sys.stderr, flush=True)
+    threading.Thread(target=heartbeat, daemon=True).start()
+
+    n_tr, n_va = int(args.clips * 0.8), int(args.clips * 0.1)
+    cpu_line, frontend_info = None, None
+    if args.stub:
+        T, F = 101, 40
+        Xtr = ytr = Xva = yva = None
+    else:
+        from cmoop_audio_processing_amd import PopulationEvaluator, _lib, frontend
+        # ---- untimed setup: synthetic clips -> HIP front end -> StandardScaler (nsga_penalty quirk Q1: refit per split)
+        wav, y = synth_waveforms(args.clips, args.classes, 1234, dev)
+        frontend.log_mel(wav[:64])                       # warm-up (code object load, tables)
+        torch.cuda.synchronize()
+        t_fe = time.perf_counter()
+        feats = frontend.log_mel(wav)                    # synchronous: returns after the kernel finished
+        t_fe = time.perf_counter() - t_fe
+        fe_bytes = wav.numel() * 4 + feats.numel() * 4   # algorithmic HBM bytes: clips in + log-mel out
+        frontend_info = {"clips": int(args.clips), "ms": round(t_fe * 1e3, 3), "clips_per_s": round(args.clips / t_fe),
+                         "algorithmic_GBps": round(fe_bytes / t_fe / 1e9, 1), "hbm_peak_GBps": 8000,
+                         "frac_of_hbm_peak": round(fe_bytes / t_fe / 8e12, 4)}
+        del wav
+        Xtr, ytr = feats[:n_tr].contiguous(), y[:n_tr].contiguous()
+        Xva, yva = feats[n_tr:n_tr + n_va].contiguous(), y[n_tr:n_tr + n_va].contiguous()
+        del feats
+        frontend.prepare_dataset(Xtr, Xva, None, mode="refit")
+        T, F = int(Xtr.shape[1]), int(Xtr.shape[2])
+
     n_pop = args.pop * (world if args.weak else 1)
     rng = random.Random(args.seed)          # initialize_population: random.choice per gene (nsga_penalty.py:402-415)
     pop = [G.random_hparams(rng) for _ in range(n_pop)]
     genes = [G.normalize_hparams(hp) for hp in pop]
 
+    # ---- CPU baseline FIRST (rank 0, N=1): bounded, and no timeout later in the run can lose it
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub:
+        phase["name"] = "cpu baseline"
+        xs, ys = Xtr[:64].cpu().numpy(), ytr[:64].cpu().numpy()
+        cpu_line = cpu_baseline(genes, variant, args.classes, T, F, n_tr, n_va, args.epochs, xs, ys, budget_s=args.cpu_baseline_s)
+
+    cfg = EvalConfig.preset("nsga_penalty", variant=args.variant, classes=args.classes, epochs=args.epochs,
+                            early_stop=False, seed=args.seed, n_slots=args.slots, profile_every=args.profile_every,
+                            schedule=args.schedule)
+    if args.stub:
+        ev = StubEvaluator(cfg, variant, args.classes, T, F, args.stub_ms_per_gflop)
+        ev_warm = ev
+    else:
+        ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+        # warm-up evaluator: same population, one epoch on the first few hundred clips (every kernel family of every
+        # candidate gets loaded and its buffers enter the cache; buffer sizes depend on the batch, not on N)
+        from dataclasses import replace
+        wn, wv = min(n_tr, 8 * cfg.batch), min(n_va, 2 * cfg.eval_batch)
+        ev_warm = PopulationEvaluator(Xtr[:wn], ytr[:wn], Xva[:wv], yva[:wv], replace(cfg, epochs=1, profile_every=0))
+
     def barrier():
-        torch.cuda.synchronize()
+        if not args.stub:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not args.stub:
+                torch.cuda.synchronize()
 
-    # heartbeat on stderr (stdout carries only the JSON line): long steps must not look hung
-    import threading
-    stop_hb = threading.Event()
+    def agree(value, op):
+        """the same float on every rank (MAX / MIN over ranks); outside N=1 one tiny all_reduce"""
+        if world == 1:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
 
-    def heartbeat():
-        t_hb = time.perf_counter()
-        while not stop_hb.wait(60.0):
-            print(f"[bench rank {rank}] running, {time.perf_counter() - t_hb:.0f} s", file=sys.stderr, flush=True)
-    threading.Thread(target=heartbeat, daemon=True).start()
+    phase["name"] = "warm-up"
+    warm_done = 0
+    for _ in range(min(args.warmup, 2)):
+        ev_warm.compute_objectives_and_constraints(pop)
+        warm_done += 1
+    if not args.stub:
+        _lib.check(_lib.lib().cmoop_profile_reset())
 
-    for _ in range(args.warmup):
-        ev.compute_objectives_and_constraints(pop)
-    _lib.check(_lib.lib().cmoop_profile_reset())
+    # ---- timed region: barrier + sync on both sides, whole generations, MAX over ranks
+    reserve_s = min(25.0, 0.1 * args.budget_s)         # isolated-kernel leg + JSON after the timed region
+    deadline = args.budget_s - reserve_s
+    phase["name"] = "timed generation 1"
     barrier()
     t0 = time.perf_counter()
-    res = None
-    for _ in range(args.steps):
+    res = ev.compute_objectives_and_constraints(pop)
+    if not args.stub:
+        torch.cuda.synchronize()
+    first = agree(time.perf_counter() - t0, dist.ReduceOp.MAX if world > 1 else None)
+    steps = int(agree(plan_steps(first, since_start(), deadline, max(1, args.steps)), dist.ReduceOp.MIN if world > 1 else None))
+    for k in range(1, steps):
+        phase["name"] = f"timed generation {k + 1} of {steps}"
         res = ev.compute_objectives_and_constraints(pop)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = agree(time.perf_counter() - t0, dist.ReduceOp.MAX if world > 1 else None)
+    n_ranks_seen = int(agree(1.0, dist.ReduceOp.SUM)) if world > 1 else 1
+    phase["name"] = "roofline legs"
 
     # ---- roofline of the dominant MFMA kernel, from HIP events recorded inside the timed region
-    L = _lib.lib()
-    cnt = C.c_int32()
-    _lib.check(L.cmoop_profile_count(C.byref(cnt)))
-    entries = []
-    for i in range(cnt.value):
-        name = C.create_string_buffer(128)
-        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
-        _lib.check(L.cmoop_profile_entry(i, name, 128, C.byref(n), C.byref(ms), C.byref(fl)))
-        entries.append({"kernel": name.value.decode(), "launches": n.value, "ms": ms.value, "flops": fl.value})
     roofline = None
-    if entries:
-        # dominant = the instantiation that carries the most algorithmic FLOPs of the step (with 8 candidates in
-        # flight, total sampled time instead picks whichever long-grid kernel shared the chip with most others)
-        dom = max(entries, key=lambda e: e["flops"])
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        tot_ms = sum(e["ms"] for e in entries)
-        tot_fl = sum(e["flops"] for e in entries)
-        roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "traffic_note": "PMC needs its own rocprofv3 passes (one counter each), so it is not collected in this run: "
-                                    "profiles/r01_pmc_fetch_write_final_kernels.csv holds FETCH_SIZE / WRITE_SIZE of this kernel on its "
-                                    "heaviest layer shape (175 MB per launch against 68 MB algorithmic; compute-bound)",
-                    "kernel": dom["kernel"], "sampled_launches": dom["launches"],
-                    "timing": "hipEventRecord pairs (under rocprofv3)" if under_rocprof else "hipExtLaunchKernelGGL start/stop events",
-                    "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5),
-                    "all_mfma_kernels_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 3) if tot_ms > 0 else None,
-                    "per_kernel": [{"kernel": e["kernel"], "launches": e["launches"],
-                                    "avg_ms": round(e["ms"] / max(e["launches"], 1), 5),
-                                    "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else None}
-                                   for e in sorted(entries, key=lambda e: -e["ms"])]}
+    if not args.stub:
+        L = _lib.lib()
+        cnt = C.c_int32()
+        _lib.check(L.cmoop_profile_count(C.byref(cnt)))
+        entries = []
+        for i in range(cnt.value):
+            name = C.create_string_buffer(128)
+            n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+            _lib.check(L.cmoop_profile_entry(i, name, 128, C.byref(n), C.byref(ms), C.byref(fl)))
+            entries.append({"kernel": name.value.decode(), "launches": n.value, "ms": ms.value, "flops": fl.value})
+        if entries:
+            # dominant = the instantiation that carries the most algorithmic FLOPs of the step (with 8 candidates in
+            # flight, total sampled time instead picks whichever long-grid kernel shared the chip with most others)
+            dom = max(entries, key=lambda e: e["flops"])
+            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+            tot_ms = sum(e["ms"] for e in entries)
+            tot_fl = sum(e["flops"] for e in entries)
+            traffic, traffic_note = None, "no committed PMC summary found (profiles/pmc_traffic_per_kernel.json)"
+            try:
+                tj = json.load(open(TRAFFIC_FILE))
+                ent = tj["kernels"].get(dom["kernel"])
+                if ent:
+                    traffic = ent["hbm_bytes_per_launch"]
+                    traffic_note = (f"{tj['source']}: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of {dom['kernel']} on {ent['shape']} "
+                                    f"= {ent['hbm_bytes_per_launch'] / 1e6:.0f} MB per launch against {ent['algorithmic_bytes_per_launch'] / 1e6:.0f} MB "
+                                    "algorithmic; separate --pmc passes, not collected in this run")
+            except (OSError, KeyError, ValueError):
+                pass
+            roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+                        "kernel": dom["kernel"], "sampled_launches": dom["launches"],
+                        "gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 3),
+                        "timing": "hipEventRecord pairs (under rocprofv3)" if under_rocprof else "hipExtLaunchKernelGGL start/stop events",
+                        "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5),
+                        "all_mfma_kernels_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 3) if tot_ms > 0 else None,
+                        "per_kernel": [{"kernel": e["kernel"], "launches": e["launches"],
+                                        "avg_ms": round(e["ms"] / max(e["launches"], 1), 5),
+                                        "gflop_per_launch": round(e["flops"] / max(e["launches"], 1) / 1e9, 3),
+                                        "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else None}
+                                       for e in sorted(entries, key=lambda e: -e["ms"])]}
 
-    # ---- the same MFMA kernels ALONE on the GPU (single stream, after the timed region): with several
-    # candidates in flight the per-launch durations above are stretched by the kernels they share the
-    # CUs with, so they understate kernel quality; this leg is the per-kernel roofline fraction.
-    if rank == 0 and roofline is not None:
-        iso = []
-        for (B, H, W, Cin, Cout, KS) in ((64, 101, 40, 64, 64, 5), (64, 51, 20, 128, 128, 5), (64, 26, 10, 256, 256, 5)):
-            x = torch.randn((B, H, W, Cin), device=dev)
-            w = torch.randn((Cout, KS, KS, Cin), device=dev) * 0.05
-            b = torch.randn((Cout,), device=dev)
-            yb = torch.randn((B, H, W, Cout), device=dev)
-            torch.cuda.synchronize()
-            fl = 2.0 * B * H * W * Cout * KS * KS * Cin
-            ent = {"conv": f"B{B} {H}x{W} {Cin}->{Cout} k{KS}", "gflop": round(fl / 1e9, 2)}
-            for mode, nm in ((0, "fwd"), (1, "dgrad"), (2, "wgrad")):
-                ms = C.c_double()
-                _lib.check(L.cmoop_conv_time(mode, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(yb), B, H, W, Cin, Cout, KS, 20,
-                                             C.byref(ms)))
-                ent[nm + "_tflops"] = round(fl / ms.value / 1e9, 1)
-            iso.append(ent)
-        roofline["isolated_single_stream"] = iso
-        roofline["isolated_frac_best"] = round(max(max(e["fwd_tflops"], e["dgrad_tflops"], e["wgrad_tflops"]) for e in iso)
-                                               / PEAK_FP32_MFMA_TFLOPS, 4)
-        roofline["concurrent_streams"] = args.slots
+        # ---- the same MFMA kernels ALONE on the GPU (single stream, after the timed region): with several
+        # candidates in flight the per-launch durations above are stretched by the kernels they share the
+        # CUs with, so they understate kernel quality; this leg is the per-kernel roofline fraction.
+        if rank == 0 and roofline is not None:
+            iso = []
+            for (B, H, W, Cin, Cout, KS) in ((64, 101, 40, 64, 64, 5), (64, 51, 20, 128, 128, 5), (64, 26, 10, 256, 256, 5)):
+                if since_start() > args.budget_s - 8.0:
+                    break
+                x = torch.randn((B, H, W, Cin), device=dev)
+                w = torch.randn((Cout, KS, KS, Cin), device=dev) * 0.05
+                b = torch.randn((Cout,), device=dev)
+                yb = torch.randn((B, H, W, Cout), device=dev)
+                torch.cuda.synchronize()
+                fl = 2.0 * B * H * W * Cout * KS * KS * Cin
+                ent = {"conv": f"B{B} {H}x{W} {Cin}->{Cout} k{KS}", "gflop": round(fl / 1e9, 2)}
+                for mode, nm in ((0, "fwd"), (1, "dgrad"), (2, "wgrad")):
+                    ms = C.c_double()
+                    _lib.check(L.cmoop_conv_time(mode, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(yb), B, H, W, Cin, Cout, KS, 10,
+                                                 C.byref(ms)))
+                    ent[nm + "_tflops"] = round(fl / ms.value / 1e9, 1)
+                iso.append(ent)
+            if iso:
+                roofline["isolated_single_stream"] = iso
+                roofline["isolated_frac_best"] = round(max(max(e["fwd_tflops"], e["dgrad_tflops"], e["wgrad_tflops"]) for e in iso) / peak, 4)
+            roofline["concurrent_streams"] = args.slots
 
+    rc = 0
     if rank == 0:
-        evals = n_pop * args.steps
+        evals = n_pop * steps
         value = evals / (elapsed / 3600.0)
-        work = sum(G.eval_flops(g, variant, args.classes, T, F, n_tr, n_va, args.epochs, 1) for g in genes) * args.steps
+        work = sum(G.eval_flops(g, variant, args.classes, T, F, n_tr, n_va, args.epochs, 1) for g in genes) * steps
         if roofline is not None:   # chip-level view: all algorithmic conv/dense FLOPs of the step / wall time
-            roofline["aggregate_timed_region"] = {"achieved": round(work / elapsed / 1e12, 2),
-                                                  "frac": round(work / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+            roofline["aggregate_timed_region"] = {"achieved": round(work / elapsed / 1e12 / world, 2),
+                                                  "frac": round(work / elapsed / 1e12 / world / peak, 4),
+                                                  "note": "all algorithmic conv+dense FLOPs of the timed region / wall time / GPUs"}
+        per_rank = [0] * world
+        for r_ in getattr(ev, "last_rank_of", []) or []:
+            if 0 <= r_ < world:
+                per_rank[r_] += 1
         line = {
             "metric": "candidate-net evals/hour (pop=40, GSC-v2)", "value": round(value, 2), "unit": "candidate-evals/hour",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 2),
+            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": steps, "steps_requested": args.steps, "warmup": warm_done,
+            "warmup_requested": args.warmup,
+            "warmup_kind": "light pass: whole population, 1 epoch on the first 512 train / 512 val clips (loads every kernel, fills the buffer cache)",
+            "ms_per_step": round(elapsed * 1e3 / steps, 2),
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 operands as 3 x bf16 (opt-in bf16x3 mode, fp32-accurate)",
                       "bf16": "bf16 operands, f32 accumulate (opt-in bf16-train mode)"}[args.gemm_mode],
-            "data": "synthetic",
+            "data": "stub (harness rehearsal, NOT a measurement)" if args.stub else "synthetic",
             "config": {"workload": f"pop={n_pop} gen=1 fitness eval (topology {args.variant}, {args.classes} classes): "
                                    f"HIP log-mel front end (untimed) + tiny-CNN train E={args.epochs} fixed epochs, "
                                    f"batch 64, N_train={n_tr}, N_val={n_va}, features {T}x{F}",
                        "population": n_pop, "epochs_per_candidate": args.epochs, "n_train": n_tr, "n_val": n_va,
-                       "slots_per_gpu": args.slots, "parallelism": f"candidates sharded over {world} GPU(s), LPT by FLOPs"},
+                       "slots_per_gpu": args.slots,
+                       "parallelism": f"candidates over {world} GPU(s): " + ("one shared longest-first queue (c10d store counter)"
+                                                                             if args.schedule == "dynamic" else "LPT buckets by closed-form FLOPs")
+                                      + ", one all_gather of objective vectors per generation",
+                       "candidates_per_rank_last_step": per_rank},
+            "budget": {"budget_s": args.budget_s, "seconds_since_start_at_print": None, "first_step_s": round(first, 2)},
             "whole_job_tflops": round(work / elapsed / 1e12, 2),
             "mean_val_accuracy": round(float(np.mean([-r["objs"][0] for r in res])), 4),
             "frontend_untimed": frontend_info,
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            xs = Xtr[:64].cpu().numpy()
-            ys = ytr[:64].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(genes, variant, args.classes, T, F, n_tr, n_va, args.epochs, xs, ys)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
+        line["budget"]["seconds_since_start_at_print"] = round(since_start(), 1)
         print(json.dumps(line), flush=True)
+        if n_ranks_seen != args.gpus:
+            print(f"bench.py: {n_ranks_seen} ranks took part, --gpus {args.gpus}", file=sys.stderr)
+            rc = 2
+    stop_hb.set()
     if world > 1:
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

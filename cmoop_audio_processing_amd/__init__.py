@@ -10,7 +10,7 @@ first use and there is no CPU fallback.
 from . import genes  # noqa: F401
 from .evaluator import (AudioNASProblem, EvalConfig, PopulationEvaluator, calculate_fpr,  # noqa: F401
                         compute_model_size_mb, compute_objectives_and_constraints, evaluate_individual, install,
-                        sharded_map)
+                        queued_map, sharded_map)
 
 __all__ = ["genes", "EvalConfig", "PopulationEvaluator", "AudioNASProblem", "install", "evaluate_individual",
-           "compute_objectives_and_constraints", "compute_model_size_mb", "calculate_fpr", "sharded_map"]
+           "compute_objectives_and_constraints", "compute_model_size_mb", "calculate_fpr", "sharded_map", "queued_map"]

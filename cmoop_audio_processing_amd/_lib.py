@@ -40,6 +40,10 @@ class DatasetStruct(C.Structure):
                 ("T", C.c_int32), ("F", C.c_int32)]
 
 
+#: cmoop_next_fn (include/cmoop.h): int32_t (*)(void* ctx)
+NEXT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p)
+
+
 def build(verbose: bool = False) -> str:
     """Compile libcmoop_hip.so for gfx950 in-tree (make; hipcc cross-compiles on CPU-only hosts)."""
     jobs = str(min(8, os.cpu_count() or 1))

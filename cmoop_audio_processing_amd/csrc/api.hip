@@ -53,6 +53,15 @@ static NetConfig to_cfg(const cmoop_config* c) {
     return n;
 }
 
+static ConvGeom make_geom(int B, int H, int W, int Cin, int Cout, int KS, int stride) {
+    ConvGeom g;
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.KH = g.KW = KS; g.stride = stride;
+    g.OH = (H + stride - 1) / stride; g.OW = (W + stride - 1) / stride;
+    g.pad_t = std::max((g.OH - 1) * stride + KS - H, 0) / 2;
+    g.pad_l = std::max((g.OW - 1) * stride + KS - W, 0) / 2;
+    return g;
+}
+
 extern "C" {
 
 int cmoop_abi_version(void) { return CMOOP_ABI_VERSION; }
@@ -96,6 +105,38 @@ int cmoop_eval_population(const cmoop_config* cfg, const cmoop_dataset* ds, cons
             if (val_loss) val_loss[i] = r[i].val_loss;
             if (seconds) seconds[i] = r[i].seconds;
         }
+    });
+}
+
+int cmoop_eval_population_pull(const cmoop_config* cfg, const cmoop_dataset* ds, const int32_t* genes, const uint32_t* seeds,
+                               int32_t n, cmoop_next_fn next, void* ctx, double* acc, double* size_mb, double* fpr,
+                               int32_t* epochs_run, double* val_loss, double* seconds, int32_t* evaluated) {
+    return guard([&] {
+        CMOOP_REQUIRE(ds && genes && seeds && next && evaluated, "NULL argument");
+        CMOOP_REQUIRE(n >= 0, "negative population size");
+        NetConfig c = to_cfg(cfg);
+        Dataset d;
+        d.x_train = ds->x_train; d.y_train = ds->y_train; d.n_train = ds->n_train;
+        d.x_val = ds->x_val; d.y_val = ds->y_val; d.n_val = ds->n_val; d.T = ds->T; d.F = ds->F;
+        CMOOP_REQUIRE(n == 0 || (d.x_train && d.y_train && d.x_val && d.y_val), "dataset pointers are NULL");
+        std::vector<EvalResult> r(n);
+        eval_population(c, d, genes, seeds, n, r.data(), [&]() { return (int)next(ctx); });
+        for (int i = 0; i < n; ++i) {
+            evaluated[i] = r[i].evaluated;
+            if (acc) acc[i] = r[i].acc;
+            if (size_mb) size_mb[i] = r[i].size_mb;
+            if (fpr) fpr[i] = r[i].fpr;
+            if (epochs_run) epochs_run[i] = r[i].epochs_run;
+            if (val_loss) val_loss[i] = r[i].val_loss;
+            if (seconds) seconds[i] = r[i].seconds;
+        }
+    });
+}
+
+int cmoop_wgrad_slices(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t* out) {
+    return guard([&] {
+        CMOOP_REQUIRE(out && B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1 && KS >= 1 && stride >= 1, "bad conv shape");
+        *out = wgrad_slices(make_geom(B, H, W, Cin, Cout, KS, stride));
     });
 }
 
@@ -236,14 +277,6 @@ int cmoop_epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* o
 }
 
 // ---- kernel-level ---------------------------------------------------------------
-static ConvGeom make_geom(int B, int H, int W, int Cin, int Cout, int KS, int stride) {
-    ConvGeom g;
-    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.KH = g.KW = KS; g.stride = stride;
-    g.OH = (H + stride - 1) / stride; g.OW = (W + stride - 1) / stride;
-    g.pad_t = std::max((g.OH - 1) * stride + KS - H, 0) / 2;
-    g.pad_l = std::max((g.OW - 1) * stride + KS - W, 0) / 2;
-    return g;
-}
 
 int cmoop_conv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t H, int32_t W, int32_t Cin,
                    int32_t Cout, int32_t KS, int32_t stride, int32_t relu) {
@@ -287,10 +320,11 @@ int cmoop_conv_bwd(const float* x, const float* w, const float* dy, float* dx, f
         }
         const ConvGeom g = make_geom(B, H, W, Cin, Cout, KS, stride);
         float *wg = nullptr, *red = nullptr, *wd = nullptr, *sk = nullptr;
-        CMOOP_HIP(hipMalloc(&wg, (size_t)wgrad_slices(g) * g.Cout * (g.K() + 1) * 4));
+        const size_t wg_floats = (size_t)wgrad_slices(g) * g.Cout * (g.K() + 1);
+        CMOOP_HIP(hipMalloc(&wg, wg_floats * 4));
         CMOOP_HIP(hipMalloc(&red, ((size_t)1024 * 2 * Cout + 2 * Cout + 64) * 4));
         CMOOP_HIP(hipMalloc(&wd, (size_t)g.Cout * g.K() * 4));
-        conv_backward_weights(x, dy, dw, db, g, wg, red, s, nullptr);
+        conv_backward_weights(x, dy, dw, db, g, wg, wg_floats, s, nullptr);
         if (dx) {
             int accumulate = 0;
             if (stride != 1) {

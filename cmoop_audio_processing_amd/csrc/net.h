@@ -5,6 +5,7 @@
 #pragma once
 #include "kernels.h"
 #include <atomic>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -45,8 +46,9 @@ struct GemmHook {   // brackets every MFMA GEMM launch (HIP-event sampling)
     virtual void end(int code) = 0;
     virtual ~GemmHook() {}
 };
+// wgrad_ws holds wgrad_ws_floats floats; the slice count is clamped to what fits (never written past)
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
-                           float* red_ws, hipStream_t s, GemmHook* hook, int mode = GEMM_DEFAULT);
+                           size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode = GEMM_DEFAULT);
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
                         float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws = nullptr,
                         size_t sk_floats = 0, int mode = GEMM_DEFAULT);
@@ -144,14 +146,18 @@ class Net : public GemmHook {
 struct EvalResult {
     double acc = 0, size_mb = 0, fpr = 0, val_loss = 0, seconds = 0;
     int epochs_run = 0;
+    int evaluated = 0;   // 1 when THIS call trained the candidate (always, unless a pull callback handed it to another rank)
 };
 
 // train-to-early-stop + readouts for one candidate (evaluate_individual, nsga_penalty.py:368-395)
 EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Dataset& ds, uint32_t seed, hipStream_t stream);
 // the population loop (compute_objectives_and_constraints, nsga_penalty.py:418-442): n_slots
 // candidates in flight on their own HIP streams, longest-first
+// pull (optional): called by the worker threads (concurrently) for the next candidate index, < 0 = queue exhausted --
+// lets several ranks drain ONE longest-first queue (cross-rank dynamic scheduling, evaluator.py); without it the
+// n candidates are taken longest-first from a process-local counter.
 void eval_population(const NetConfig& cfg, const Dataset& ds, const int32_t* genes, const uint32_t* seeds, int n,
-                     EvalResult* out);
+                     EvalResult* out, const std::function<int()>& pull = {});
 
 double fpr_from_confusion(const int64_t* cm, int C, int variant);
 void epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out);

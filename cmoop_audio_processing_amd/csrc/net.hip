@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <numeric>
 #include <thread>
@@ -340,7 +341,13 @@ void Net::build_plan() {
         }
         if (op.kind == OP_CONV || op.kind == OP_DENSE) {
             const ConvGeom g = geom_of(op, cfg_.batch);
-            wgrad_ws_floats_ = std::max(wgrad_ws_floats_, (size_t)wgrad_slices(g) * g.Cout * (g.K() + 1));
+            // the slice count is NOT monotone in the batch rows (a smaller M can flip the K-tile width and the
+            // co-resident workgroup count, so a partial last batch may ask for MORE slices than the full one):
+            // size the slab workspace for the worst train batch 1..cfg.batch
+            for (int b = 1; b <= cfg_.batch; ++b) {
+                const ConvGeom gb = geom_of(op, b);
+                wgrad_ws_floats_ = std::max(wgrad_ws_floats_, (size_t)wgrad_slices(gb) * gb.Cout * (gb.K() + 1));
+            }
             wd_ws_floats_ = std::max(wd_ws_floats_, (size_t)g.Cout * g.K());
             // split-K slabs: forward (train and inference batch) and dgrad (input-shaped output)
             splitk_ws_floats_ = std::max(splitk_ws_floats_, igemm_splitk_workspace(g));
@@ -434,9 +441,13 @@ void Net::end(int code) {
 
 // dW[N][K] and db[N] of a conv / dense layer: MFMA split over row slices, then a fixed-order slice sum
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
-                           float* red_ws, hipStream_t s, GemmHook* hook, int mode) {
+                           size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode) {
     const int M = g.M(), N = g.Cout, K = g.K();
-    const int S = wgrad_slices(g);
+    int S = wgrad_slices(g);
+    // never write past the slab workspace: fewer slices is always correct (each slice is a row range)
+    const size_t per_slice = (size_t)N * (K + 1);
+    if (S > 1 && (size_t)S * per_slice > wgrad_ws_floats) S = (int)std::max<size_t>(1, wgrad_ws_floats / per_slice);
+    CMOOP_REQUIRE(S == 1 || (size_t)S * per_slice <= wgrad_ws_floats, "wgrad slab workspace too small");
     // slices are laid out [S][N*K + N] (kernel partials then bias partials): when dB directly follows dW
     // (the trainer's arena) a single fixed-order reduction produces both; one slice writes in place.
     const size_t NK = (size_t)N * K, stride = NK + N;
@@ -454,7 +465,6 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
             launch_reduce_slices(wgrad_ws + NK, dB, S, N, s, (int64_t)stride);
         }
     }
-    (void)red_ws;
 }
 
 // dX of a conv / dense layer: the same implicit-GEMM kernel on dY with flip-transposed weights.
@@ -597,7 +607,7 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B) {
             // (measured, not adopted: wgrad on a low-priority side stream forked per layer and joined before Adam -- off the
             // dgrad critical path -- ran 35 % SLOWER, 65 vs 100 TFLOP/s whole-job: the cross-stream event waits cost more
             // than the overlap wins)
-            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, red_ws_, stream_, this, op.gemm_mode);
+            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, wgrad_ws_floats_, stream_, this, op.gemm_mode);
             if (op.need_dgrad)
                 conv_backward_data(dY, params_ + op.w_off, ia.grad, g, wd_ws_, op.in_is_relu ? ia.data : nullptr,
                                    op.in_mask_scale, op.dgrad_accumulate, stream_, this, splitk_ws_, splitk_ws_floats_, op.gemm_mode);
@@ -775,9 +785,10 @@ EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Data
 }
 
 void eval_population(const NetConfig& cfg, const Dataset& ds, const int32_t* genes, const uint32_t* seeds, int n,
-                     EvalResult* out) {
+                     EvalResult* out, const std::function<int()>& pull) {
     if (n <= 0) return;
     for (int i = 0; i < n; ++i) validate_gene(genes + 6 * i);
+    for (int i = 0; i < n; ++i) out[i].evaluated = 0;
     // longest first (closed-form FLOPs) so the tail of the generation is made of cheap candidates
     std::vector<int> order(n);
     std::iota(order.begin(), order.end(), 0);
@@ -796,11 +807,19 @@ void eval_population(const NetConfig& cfg, const Dataset& ds, const int32_t* gen
             CMOOP_HIP(hipSetDevice(dev));
             CMOOP_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
             for (;;) {
-                const int j = next.fetch_add(1);
-                if (j >= n) break;
                 { std::lock_guard<std::mutex> l(err_mu); if (!err.empty()) break; }
-                const int i = order[j];
+                int i;
+                if (pull) {   // cross-rank queue: the caller hands out candidate indices (shared counter on the c10d store)
+                    i = pull();
+                    if (i < 0) break;
+                    CMOOP_REQUIRE(i < n, "pull callback returned an index outside the population");
+                } else {
+                    const int j = next.fetch_add(1);
+                    if (j >= n) break;
+                    i = order[j];
+                }
                 out[i] = run_candidate(genes + 6 * i, cfg, ds, seeds[i], stream);
+                out[i].evaluated = 1;
             }
         } catch (const std::exception& e) {
             std::lock_guard<std::mutex> l(err_mu);

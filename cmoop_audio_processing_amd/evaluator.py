@@ -19,8 +19,10 @@ reference runs unchanged.  Per-script quirks are selected by
 
 Multi-GPU: under ``torch.distributed`` every rank runs the same seeded host
 loop; ``compute_objectives_and_constraints`` shards the generation's candidates
-by LPT on closed-form FLOPs, evaluates its shard on its GPU and exchanges the
-objective vectors with ONE all_gather (RCCL over xGMI) -- no other collective.
+over the ranks -- by default through ONE shared longest-first queue (a fetch-add
+counter on the c10d store, ``queued_map``), optionally by static LPT buckets on
+closed-form FLOPs (``sharded_map``) -- and exchanges the objective vectors with ONE
+all_gather (RCCL over xGMI) per generation; no other collective.
 """
 from __future__ import annotations
 
@@ -63,6 +65,10 @@ class EvalConfig:
     dropout: float = 0.3
     shuffle: bool = True
     verbose: bool = False         # print the reference's per-candidate lines
+    # multi-GPU candidate placement: "dynamic" = every rank's workers drain ONE longest-first queue (a fetch-add
+    # counter on the c10d store; balances early-stopped runs whose epoch counts are unknown in advance);
+    # "static" = LPT buckets by closed-form FLOPs.  Results are bit-identical either way (per-candidate seeds).
+    schedule: str = "dynamic"
 
     @staticmethod
     def preset(script: str, **over) -> "EvalConfig":
@@ -162,6 +168,74 @@ def sharded_map(local_fn: Callable[[List[int]], np.ndarray], costs: Sequence[flo
     return out
 
 
+_queue_serial = [0]   # queue keys are unique per (evaluator, generation); SPMD ranks construct evaluators in the same order
+
+
+def _default_store():
+    import torch.distributed.distributed_c10d as c10d
+    return c10d._get_default_store()
+
+
+def queued_map(local_pull_fn: Callable[[Callable[[], int]], Dict[int, Sequence[float]]], costs: Sequence[float], width: int,
+               key: str, device: str = "cpu") -> np.ndarray:
+    """Evaluate items 0..n-1 across the ranks through ONE shared longest-first queue.
+
+    Every rank's workers call ``pull()`` -- a fetch-add on the process group's c10d store (``store.add(key, 1)``,
+    no collective) -- for the position in the cost-sorted order of the next item to evaluate; ``pull() < 0`` means
+    the queue is drained.  ``local_pull_fn(pull) -> {index: row[width]}`` runs this rank's workers.  The results are
+    then exchanged with ONE all_gather of ``[n, width+1]`` float64 per rank (last column = "I evaluated it").
+    This is the cross-rank twin of the in-GPU queue of ``eval_population`` (csrc/net.hip): with early stopping the
+    epochs a candidate runs are unknown in advance (7...173 observed), which static LPT buckets cannot balance.
+    Without a process group the queue is a local counter.
+    """
+    import itertools
+    import threading
+    n = len(costs)
+    order = sorted(range(n), key=lambda i: (-costs[i], i))      # longest first, ties by index (same on every rank)
+    dist = _dist()
+    multi = dist is not None and dist.get_world_size() > 1
+    if multi:
+        store = _default_store()
+
+        def pull() -> int:
+            j = int(store.add(key, 1)) - 1
+            return order[j] if j < n else -1
+    else:
+        ctr, lock = itertools.count(), threading.Lock()
+
+        def pull() -> int:
+            with lock:
+                j = next(ctr)
+            return order[j] if j < n else -1
+    mine = local_pull_fn(pull) if n else {}
+    local = np.full((n, width + 1), np.nan, dtype=np.float64)
+    local[:, width] = 0.0
+    for i, row in mine.items():
+        local[i, :width] = np.asarray(row, dtype=np.float64).reshape(width)
+        local[i, width] = 1.0
+    if not multi:
+        if n and not bool((local[:, width] == 1.0).all()):
+            raise _lib.CmoopError("queued_map: the local workers left candidates unevaluated")
+        return local[:, :width].copy()
+    import torch
+    world = dist.get_world_size()
+    if str(dist.get_backend()).lower() == "gloo":
+        device = "cpu"
+    send = torch.from_numpy(local).to(device)
+    recv = torch.empty((world * max(n, 1), width + 1), dtype=torch.float64, device=device)
+    if n == 0:
+        send = torch.zeros((1, width + 1), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    if n == 0:
+        return np.zeros((0, width), dtype=np.float64)
+    allr = recv.cpu().numpy().reshape(world, n, width + 1)
+    owners = allr[:, :, width]
+    if not bool((owners.sum(axis=0) == 1.0).all()):
+        raise _lib.CmoopError(f"queued_map: every candidate must be evaluated by exactly one rank, got {owners.sum(axis=0)}")
+    who = owners.argmax(axis=0)
+    return allr[who, np.arange(n), :width].copy()
+
+
 class PopulationEvaluator:
     """Holds the resident dataset + protocol and evaluates candidates on this rank's GPU."""
 
@@ -179,6 +253,9 @@ class PopulationEvaluator:
             raise ValueError("features and labels differ in length")
         self.T, self.F = int(self.X_train.shape[1]), int(self.X_train.shape[2])
         self.evals_done = 0          # seeds are cfg.seed + running candidate index (same on every SPMD rank)
+        _queue_serial[0] += 1
+        self._queue_prefix, self._generation = f"cmoop/queue/{_queue_serial[0]}", 0
+        self.last_rank_of: List[int] = []   # which rank trained each candidate of the last generation
         self.last_epochs_run: List[int] = []
         self.last_seconds: List[float] = []
         torch.cuda.synchronize()
@@ -210,6 +287,35 @@ class PopulationEvaluator:
         out[:, 0], out[:, 1], out[:, 2], out[:, 3], out[:, 4] = acc, size, fpr, ep, secs
         return out
 
+    def evaluate_genes_pull(self, gene_list: Sequence[Sequence[int]], seeds: Sequence[int], pull: Callable[[], int]) -> Dict[int, np.ndarray]:
+        """Train the candidates ``pull()`` hands to this GPU's worker threads (cfg.n_slots of them call it
+        concurrently, from C++); returns {index: (accuracy, size_mb, fpr, epochs_run, seconds)}."""
+        n = len(gene_list)
+        if n == 0:
+            return {}
+        for g in gene_list:
+            G.validate_gene(g)
+        genes = np.ascontiguousarray(np.asarray(gene_list, dtype=np.int32).reshape(n, 6))
+        sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).astype(np.uint32))
+        acc, size, fpr, secs = (np.zeros(n, np.float64) for _ in range(4))
+        ep, done = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        cfg, ds = self.config.to_struct(), self._dataset()
+        errors: List[BaseException] = []
+
+        def _next(_ctx):
+            try:
+                return int(pull())
+            except BaseException as e:      # never let an exception cross the C boundary: end this worker, re-raise below
+                errors.append(e)
+                return -1
+        cb = _lib.NEXT_FN(_next)
+        _lib.check(_lib.lib().cmoop_eval_population_pull(
+            C.byref(cfg), C.byref(ds), _lib.ptr(genes), _lib.ptr(sd), C.c_int32(n), cb, None, _lib.ptr(acc), _lib.ptr(size),
+            _lib.ptr(fpr), _lib.ptr(ep), None, _lib.ptr(secs), _lib.ptr(done)))
+        if errors:
+            raise errors[0]
+        return {int(i): np.array([acc[i], size[i], fpr[i], ep[i], secs[i]], dtype=np.float64) for i in np.nonzero(done)[0]}
+
     # -- the reference's surface ------------------------------------------------
     def evaluate_individual(self, hparams: Dict):
         """(accuracy, size_mb, fpr) of one candidate -- nsga_penalty.py:368-395."""
@@ -227,8 +333,24 @@ class PopulationEvaluator:
         seeds = [self.config.seed + self.evals_done + i for i in range(n)]
         v = G.VARIANT_NAMES[self.config.variant]
         costs = [float(G.fwd_flops_per_sample(g, v, self.config.classes, self.T, self.F)) for g in gl]
-        res = sharded_map(lambda idx: self.evaluate_genes([gl[i] for i in idx], [seeds[i] for i in idx]),
-                          costs, 5, device="cuda") if n else np.zeros((0, 5))
+        dist = _dist()
+        multi = dist is not None and dist.get_world_size() > 1
+        self._generation += 1
+        if not n:
+            res = np.zeros((0, 6))
+            if multi:   # keep the SPMD ranks in step: the empty generation still does its (empty) exchange
+                queued_map(lambda pull: {}, [], 6, f"{self._queue_prefix}/{self._generation}", device="cuda")
+        elif not multi:
+            res = np.concatenate([self.evaluate_genes(gl, seeds), np.zeros((n, 1))], axis=1)
+        elif self.config.schedule == "static":     # LPT buckets by closed-form FLOPs (fixed-epoch throughput runs)
+            rank = float(dist.get_rank())
+            res = sharded_map(lambda idx: np.concatenate([self.evaluate_genes([gl[i] for i in idx], [seeds[i] for i in idx]),
+                                                          np.full((len(idx), 1), rank)], axis=1), costs, 6, device="cuda")
+        else:                                       # one longest-first queue drained by all ranks (default)
+            rank = float(dist.get_rank())
+            res = queued_map(lambda pull: {i: np.append(r, rank) for i, r in self.evaluate_genes_pull(gl, seeds, pull).items()},
+                             costs, 6, f"{self._queue_prefix}/{self._generation}", device="cuda")
+        self.last_rank_of = [int(r) for r in res[:, 5]]
         self.evals_done += n
         self.last_epochs_run = [int(e) for e in res[:, 3]]
         self.last_seconds = [float(s) for s in res[:, 4]]

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CMOOP_ABI_VERSION 1
+#define CMOOP_ABI_VERSION 2
 
 /* topologies hidden behind the reference's build_model(hparams) */
 #define CMOOP_VARIANT_A 0 /* "deep":    nsga_penalty.py:225-334, mobo_penalty.py:128-194 */
@@ -92,6 +92,22 @@ int cmoop_fwd_flops(const int32_t gene[6], int32_t variant, int32_t classes, int
 int cmoop_eval_population(const cmoop_config* cfg, const cmoop_dataset* ds, const int32_t* genes /* [n][6] */,
                           const uint32_t* seeds /* [n] */, int32_t n, double* acc, double* size_mb, double* fpr,
                           int32_t* epochs_run, double* val_loss, double* seconds);
+
+/* The same loop drained through a caller-supplied queue: the library's worker threads (cfg.n_slots of them,
+ * concurrently) call next(ctx) for the index in [0,n) of the next candidate to train; a negative return ends that
+ * worker.  Several processes (one per GPU) that share one counter therefore drain ONE longest-first queue, which
+ * balances the early-stopped protocol where epochs run are unknown in advance (the reference's loop is serial,
+ * nsga_penalty.py:426-427; it has no counterpart).  evaluated[i] = 1 for the candidates this call trained; the
+ * other outputs of un-evaluated candidates are left untouched. */
+typedef int32_t (*cmoop_next_fn)(void* ctx);
+int cmoop_eval_population_pull(const cmoop_config* cfg, const cmoop_dataset* ds, const int32_t* genes /* [n][6] */,
+                               const uint32_t* seeds /* [n] */, int32_t n, cmoop_next_fn next, void* ctx, double* acc,
+                               double* size_mb, double* fpr, int32_t* epochs_run, double* val_loss, double* seconds,
+                               int32_t* evaluated /* [n], required */);
+
+/* host-only: number of row slices the weight-gradient kernel splits a conv/dense layer into (workspace sizing;
+ * NOT monotone in B -- tests pin that the trainer sizes its slab workspace for the worst batch 1..cfg.batch) */
+int cmoop_wgrad_slices(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t* out);
 
 /* calculate_fpr on host label arrays (nsga_penalty.py:351-364 and variants) */
 int cmoop_calculate_fpr(const int32_t* y_true, const int32_t* y_pred, int64_t n, int32_t classes, int32_t fpr_variant,

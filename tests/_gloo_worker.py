@@ -6,7 +6,7 @@ import numpy as np
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cmoop_audio_processing_amd import genes as G, sharded_map  # noqa: E402
+from cmoop_audio_processing_amd import genes as G, queued_map, sharded_map  # noqa: E402
 
 
 def main():
@@ -34,6 +34,54 @@ def main():
     assert out1.shape == (1, 1) and out1[0, 0] == 7.0
     out0 = sharded_map(lambda idx: np.zeros((len(idx), 2)), [], 2, device="cpu")
     assert out0.shape == (0, 2)
+    # ---- cross-rank dynamic queue (queued_map): adversarial ACTUAL costs the closed-form estimate cannot see --
+    # 41 candidates of equal estimated cost, one of which really takes 20x (an early-stopped run that converges
+    # slowly).  Static LPT buckets put 20/21 candidates on each rank -> one rank needs ~40 units, the other 20;
+    # the shared longest-first queue lets the other rank drain the rest: both finish within 10 % of each other.
+    import time
+    unit = 0.01
+    actual = [1.0] * 41
+    actual[17] = 20.0
+    est = [1.0] * 41
+
+    def row(i):
+        return [float(i), float(i * i), 0.5]
+
+    def run_static():
+        t0 = time.perf_counter()
+        out = sharded_map(lambda idx: np.array([(time.sleep(actual[i] * unit), row(i))[1] for i in idx]).reshape(len(idx), 3),
+                          est, 3, device="cpu")
+        return out, time.perf_counter() - t0
+
+    busy = {}
+
+    def local_pull(pull):
+        t0 = time.perf_counter()
+        mine = {}
+        while True:
+            i = pull()
+            if i < 0:
+                break
+            time.sleep(actual[i] * unit)
+            mine[i] = row(i)
+        busy["t"] = time.perf_counter() - t0
+        return mine
+
+    dist.barrier()
+    out_q = queued_map(local_pull, est, 3, "test/queue/1", device="cpu")
+    out_s, _ = run_static()
+    assert np.array_equal(out_q, out_s) and out_q[:, 0].tolist() == list(range(41))        # bit-identical to the static path
+    import torch
+    t = torch.tensor([busy["t"]], dtype=torch.float64)
+    ts = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(ts, t)
+    tq = [float(x) for x in ts]
+    assert max(tq) <= 1.10 * min(tq) + 2 * unit, f"queue left the ranks unbalanced: {tq}"
+    assert max(tq) < 0.8 * 41 * unit, f"queue no better than a static split: {tq}"        # static worst rank ~ 40 units
+    # empty generation and fewer candidates than ranks through the queue
+    assert queued_map(lambda pull: {}, [], 2, "test/queue/2", device="cpu").shape == (0, 2)
+    one = queued_map(lambda pull: {i: [7.0] for i in iter(pull, -1)}, [1.0], 1, "test/queue/3", device="cpu")
+    assert one.shape == (1, 1) and one[0, 0] == 7.0
     dist.barrier()
     if rank == 0:
         print("GLOO_WORKER_OK")

@@ -220,6 +220,43 @@ def test_frontend_logmel_and_standardize():
     assert np.abs(feats.cpu().numpy() - ofe.scaler_transform(out.cpu().numpy(), mean, scale)).max() < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["refit", "train_only", "none"])
+def test_prepare_dataset_modes_vs_oracle_scaler(mode):
+    """prepare_dataset's three per-script behaviours against the oracle's StandardScaler restatement:
+    'refit'      nsga_penalty.py:111,124,137 -- fit_transform on EVERY split (quirk Q1: val/test scaled by their own stats)
+    'train_only' mobo_penalty.py:69-79 -- fit on train, transform the rest
+    'none'       sa_nsga_penalty.py:61-85 -- features used unscaled (quirk Q2).
+    Tolerance 1e-5 absolute on the standardised values (float64 stats, fp32 storage)."""
+    from cmoop_audio_processing_amd import frontend as fe
+    from oracle import frontend as ofe
+    rs = np.random.RandomState(11)
+    raw = [(3.0 + 2.0 * rs.randn(n, 13, 40) * (1 + np.arange(40) / 10.0)).astype(np.float32) for n in (50, 20, 17)]
+    raw[1] += 0.7          # validation has different statistics: 'refit' and 'train_only' must differ visibly
+    d = [dev(x) for x in raw]
+    out = fe.prepare_dataset(d[0], d[1], d[2], mode=mode)
+    assert all(o is x for o, x in zip(out, d))                       # in place, same tensors returned
+    m0, s0 = ofe.scaler_fit(raw[0])
+    for i in range(3):
+        if mode == "none":
+            ref = raw[i]
+        elif mode == "refit" or i == 0:
+            ref = ofe.scaler_transform(raw[i], *ofe.scaler_fit(raw[i]))
+        else:
+            ref = ofe.scaler_transform(raw[i], m0, s0)
+        assert np.abs(d[i].cpu().numpy() - ref).max() < 1e-5, (mode, i)
+    if mode == "refit":      # every split ends with zero mean / unit variance per mel bin
+        for x in d:
+            flat = x.cpu().numpy().astype(np.float64).reshape(-1, 40)
+            assert np.abs(flat.mean(0)).max() < 1e-5 and np.abs(flat.std(0) - 1).max() < 1e-5
+    if mode == "train_only":
+        assert abs(float(d[1].mean())) > 0.05                        # val keeps its offset relative to train
+    with pytest.raises(ValueError):
+        fe.prepare_dataset(d[0], d[1], None, mode="per_split")
+    # validation-only call shape used by bench.py: X_test=None
+    a, b, c = fe.prepare_dataset(dev(raw[0]), dev(raw[1]), None, mode="refit")
+    assert c is None and np.abs(b.cpu().numpy() - ofe.scaler_transform(raw[1], *ofe.scaler_fit(raw[1]))).max() < 1e-5
+
+
 def test_frontend_edge_cases():
     from cmoop_audio_processing_amd import frontend as fe
     from oracle import frontend as ofe

@@ -43,6 +43,17 @@ def make_data(n, T, F, classes, seed):
     return X, y
 
 
+def make_split(n_train, n_val, T, F, classes, seed, noise=1.0):
+    """Train and validation drawn from the SAME class prototypes (one RandomState), so a net that fits the train
+    split generalises: validation accuracy lands in 0.6-0.95 instead of chance (the protocol tests ran on
+    splits with different prototypes, i.e. on noise predictions)."""
+    rs = np.random.RandomState(seed)
+    proto = rs.randn(classes, T, F).astype(np.float32)
+    y = rs.randint(0, classes, size=n_train + n_val).astype(np.int32)
+    X = (0.8 * proto[y] + noise * rs.randn(n_train + n_val, T, F)).astype(np.float32)
+    return X[:n_train], y[:n_train], X[n_train:], y[n_train:]
+
+
 def per_tensor_err(gene, variant, classes, a, b):
     """max-abs error of each canonical tensor relative to that tensor's max magnitude.
 
@@ -187,7 +198,7 @@ def test_birdclef_shaped_path_config3():
     acc, size_mb, fpr = ev.evaluate_individual(G.gene_to_hparams(gene))
     o_acc, o_size, o_fpr, o_epochs = ON.evaluate_individual(gene, ocfg(cfg), Xtr, ytr, Xva, yva, seed=seed)
     assert size_mb == o_size == G.model_size_mb(gene, 1, classes)
-    assert abs(acc - o_acc) <= 2.0 / len(Xva) + 1e-9 and abs(fpr - o_fpr) <= 2e-2 and abs(ev.last_epochs_run[0] - o_epochs) <= 1
+    assert abs(acc - o_acc) <= 1e-3 and abs(fpr - o_fpr) <= 1e-3 and ev.last_epochs_run[0] == o_epochs
 
 
 PROTOCOLS = [
@@ -199,23 +210,168 @@ PROTOCOLS = [
 
 @pytest.mark.parametrize("preset,gene", PROTOCOLS)
 def test_evaluate_individual_protocol_parity(preset, gene):
-    """Bounded-horizon end-to-end parity (SURVEY §7 hard part 1): 6 epochs x 4 steps with early
-    stopping active.  size_mb bit-exact; val-loss-driven epoch count equal; accuracy within
-    2/N_val and FPR within 2e-2 of the oracle (chaotic fp32 training: a single flipped
-    prediction is 1/N_val), and -- the 1e-3 gate -- metrics from IDENTICAL weights are
-    covered by test_init_step_grads_and_eval_parity (identical predictions)."""
+    """Bounded-horizon end-to-end parity at the north-star gate: |d accuracy| <= 1e-3, |d FPR| <= 1e-3, epochs_run
+    equal, size_mb bit-exact -- on a task the nets LEARN (train and validation share class prototypes; validation
+    accuracy 0.6-0.95), with early stopping, best-weight restore and the per-script read-outs active.  8 epochs x 6
+    steps; N_val = 128, so 1e-3 means identical prediction counts."""
     classes = 10 if preset != "sa_nsga_penalty" else 11
-    cfg = EvalConfig.preset(preset, classes=classes, epochs=6, patience=2, batch=32, eval_batch=64, seed=11, n_slots=1)
-    Xtr, ytr = make_data(128, 21, 12, classes, 21)
-    Xva, yva = make_data(96, 21, 12, classes, 22)
+    cfg = EvalConfig.preset(preset, classes=classes, epochs=8, patience=2, batch=32, eval_batch=64, seed=11, n_slots=1)
+    Xtr, ytr, Xva, yva = make_split(192, 128, 21, 12, classes, 21, noise=1.2)
     ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
     acc, size_mb, fpr = ev.evaluate_individual(G.gene_to_hparams(gene))
     o_acc, o_size, o_fpr, o_epochs = ON.evaluate_individual(gene, ocfg(cfg), Xtr, ytr, Xva, yva, seed=11)
     print(preset, "gpu", (acc, size_mb, fpr, ev.last_epochs_run), "oracle", (o_acc, o_size, o_fpr, o_epochs))
     assert size_mb == o_size == G.model_size_mb(gene, G.VARIANT_NAMES[cfg.variant], classes)
-    assert abs(acc - o_acc) <= 2.0 / 96 + 1e-9
-    assert abs(fpr - o_fpr) <= 2e-2
-    assert abs(ev.last_epochs_run[0] - o_epochs) <= 1
+    assert 0.5 <= o_acc <= 0.97, f"the parity task must be learnable but not saturated, oracle accuracy {o_acc}"
+    assert abs(acc - o_acc) <= 1e-3
+    assert abs(fpr - o_fpr) <= 1e-3
+    assert ev.last_epochs_run[0] == o_epochs
+
+
+def test_reference_input_shapes_at_the_boundary():
+    """The hand-over the reference actually does: features [N,T,F,1] (channel axis added by prepare_dataset,
+    nsga_penalty.py:151-153) and labels (N,1) (load_data, :74-76), as float64 / int64 numpy arrays.  Same result as
+    the squeezed float32 / int32 inputs, bit for bit."""
+    classes = 10
+    cfg = EvalConfig.preset("nsga_penalty", epochs=2, batch=32, eval_batch=64, seed=3, n_slots=1, early_stop=False)
+    Xtr, ytr, Xva, yva = make_split(96, 64, 21, 12, classes, 5)
+    hp = G.gene_to_hparams((16, 3, 1, 1, 1, 0))
+    a = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg).compute_objectives_and_constraints([hp])[0]
+    b = PopulationEvaluator(Xtr[..., None].astype(np.float64), ytr.reshape(-1, 1).astype(np.int64),
+                            Xva[..., None].astype(np.float64), yva.reshape(-1, 1).astype(np.int64),
+                            cfg).compute_objectives_and_constraints([hp])[0]
+    assert a["objs"] == b["objs"] and a["CV"] == b["CV"]
+    with pytest.raises(ValueError):
+        PopulationEvaluator(Xtr[:, :, :, None, None], ytr, Xva, yva, cfg)
+    with pytest.raises(ValueError):
+        PopulationEvaluator(Xtr, ytr[:-1], Xva, yva, cfg)
+
+
+@pytest.mark.parametrize("B", [28, 40, 51])
+def test_wgrad_workspace_partial_batches_advice_r1(B):
+    """gene (32,3,*,1,*,*) topology A at 101x40, batch 64 -- the layer 51x20 32->64 k3 asks for 98
+    wgrad slices at the full batch but 109 for B in 28..51, which overflowed a workspace sized from the full batch.
+    One train step at such a B against the oracle (gradients of every tensor), then a full-batch step on the same
+    net (the workspace must serve both)."""
+    gene, classes, seed = (32, 3, 1, 1, 1, 0), 10, 9
+    cfg = EvalConfig(variant="A", classes=classes, batch=64, eval_batch=64)
+    X, y = make_data(64, 101, 40, classes, 77)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    onet = ON.OracleNet(gene, ocfg(cfg), seed)
+    with NetSession(gene, cfg, 101, 40, seed) as net:
+        net.train_step(Xd, yd, None, row0=0, B=B)
+        onet.train_step(X[:B], y[:B])
+        gerr = per_tensor_err(gene, 0, classes, net.get_grads(), onet.grads_flat())
+        assert max(gerr.values()) < 5e-4, gerr
+        net.train_step(Xd, yd, None, row0=0, B=64)
+        onet.train_step(X, y)
+        gerr = per_tensor_err(gene, 0, classes, net.get_grads(), onet.grads_flat())
+        assert max(gerr.values()) < 2e-3, gerr        # second step: weights already differ by the first step's rounding
+
+
+def test_population_40_at_baseline_feature_size_config1():
+    """BASELINE configs[1] at full population and feature size: the 40 genes of random.Random(0) (the bench's
+    population), 101x40 features, a few hundred clips, one epoch.  Size-independent properties for all 40 --
+    size_mb bit-exact, results independent of the number of candidates in flight, the FPR-quirk bound -- plus oracle
+    parity (north-star gate 1e-3) on the three cheapest genes."""
+    import random
+    classes = 10
+    rng = random.Random(0)
+    pop = [G.random_hparams(rng) for _ in range(40)]
+    genes = [G.normalize_hparams(hp) for hp in pop]
+    Xtr, ytr, Xva, yva = make_split(256, 128, 101, 40, classes, 123, noise=1.0)
+    base = dict(epochs=1, batch=64, eval_batch=128, seed=0, early_stop=False)
+    ev8 = PopulationEvaluator(Xtr, ytr, Xva, yva, EvalConfig.preset("nsga_penalty", n_slots=8, **base))
+    res8 = ev8.compute_objectives_and_constraints(pop)
+    ev3 = PopulationEvaluator(Xtr, ytr, Xva, yva, EvalConfig.preset("nsga_penalty", n_slots=3, **base))
+    res3 = ev3.compute_objectives_and_constraints(pop)
+    assert [r["objs"] for r in res8] == [r["objs"] for r in res3]          # deterministic, slot-count independent
+    for g, r in zip(genes, res8):
+        acc, size, fpr = -r["objs"][0], r["objs"][1], r["objs"][2]
+        assert size == G.model_size_mb(g, 0, classes)                      # bit-exact (== in float64)
+        assert 0.0 <= acc <= 1.0 and 0.0 <= fpr <= 1.0 / classes + 1e-12   # nsga_penalty.py:387 quirk: FPR <= 1/C
+        assert r["CV"] == max(0.0, 0.9 - acc) + max(0.0, size - 2.5) + max(0.0, fpr - 0.1)
+    assert ev8.last_epochs_run == [1] * 40
+    cheapest = sorted(range(40), key=lambda i: G.fwd_flops_per_sample(genes[i], 0, classes, 101, 40))[:3]
+    ocf = ocfg(ev8.config)
+    for i in cheapest:
+        o_acc, o_size, o_fpr, _ = ON.evaluate_individual(genes[i], ocf, Xtr, ytr, Xva, yva, seed=i)   # seed = cfg.seed + index
+        acc, size, fpr = -res8[i]["objs"][0], res8[i]["objs"][1], res8[i]["objs"][2]
+        print(genes[i], "gpu", (acc, fpr), "oracle", (o_acc, o_fpr))
+        assert size == o_size and abs(acc - o_acc) <= 1e-3 and abs(fpr - o_fpr) <= 1e-3
+
+
+def _oracle_population_evaluator(cfg, Xtr, ytr, Xva, yva):
+    """compute_objectives_and_constraints on the oracle with the evaluator's seed convention (cfg.seed + running index)."""
+    counter = {"n": 0}
+
+    def oracle_eval(pop):
+        out = []
+        for hp in pop:
+            g = G.normalize_hparams(hp)
+            acc, size, fpr, _ = ON.evaluate_individual(g, ocfg(cfg), Xtr, ytr, Xva, yva, seed=cfg.seed + counter["n"])
+            counter["n"] += 1
+            out.append(OM.assemble(hp, acc, size, fpr, cfg.min_accuracy, cfg.max_model_size, cfg.max_fpr))
+        return out
+    return oracle_eval
+
+
+def test_sa_nsga2_35_classes_on_gpu_vs_oracle_config2():
+    """BASELINE configs[2] at reduced size: the surrogate-assisted loop of sa_nsga_penalty.py:522-637 (topology B,
+    restore_best + evaluate(), infill 0.2, Kriging surrogate on the host) driven by the GPU evaluator on a 35-class
+    task, pop 8 / gen 2 -> 8 + 2*1 true evaluations, against the same seeded loop on the oracle: the same genes must
+    be chosen for true evaluation and their objectives agree to the north-star gate."""
+    from cmoop_audio_processing_amd import surrogate as S
+    classes = 35
+    cfg = EvalConfig.preset("sa_nsga_penalty", classes=classes, epochs=4, patience=2, batch=32, eval_batch=64, seed=5, n_slots=4)
+    Xtr, ytr, Xva, yva = make_split(280, 140, 21, 12, classes, 61, noise=0.8)
+    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+    _, hist_gpu, n_gpu = S.sa_nsga2(ev.compute_objectives_and_constraints, 8, 2, infill_percent=0.2, seed=3)
+    _, hist_cpu, n_cpu = S.sa_nsga2(_oracle_population_evaluator(cfg, Xtr, ytr, Xva, yva), 8, 2, infill_percent=0.2, seed=3)
+    assert n_gpu == n_cpu == 8 + 2 * 1 and ev.evals_done == n_gpu
+    _compare_histories(hist_gpu, hist_cpu)
+
+
+def test_memetic_sa_nsga2_bf16_on_gpu_vs_oracle_config4():
+    """BASELINE configs[4] at reduced size: the full memetic method of init_sa_nsga_local.py:388-470 (LHS init,
+    Kriging surrogate, Lamarckian LCB local search, infill 0.334) with the opt-in bf16-train arithmetic
+    (compute='bf16'), pop 8 / gen 2 on the GPU evaluator vs the same loop on the bf16 oracle.  bf16 nets are not
+    bit-comparable, so the gate is: same number of true evaluations, size bit-exact per generation
+    member, and accuracies within 0.1 / hypervolume within 10 % -- the loop runs end to end on the GPU path."""
+    from cmoop_audio_processing_amd import nsga, surrogate as S
+    classes = 10
+    cfg = EvalConfig.preset("init_sa_nsga_local", classes=classes, epochs=4, patience=2, batch=32, eval_batch=64, seed=8, n_slots=4,
+                            compute="bf16")
+    Xtr, ytr, Xva, yva = make_split(192, 96, 21, 12, classes, 71, noise=1.0)
+    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+    kw = dict(infill_percent=0.334, seed=4, init="lhs", local_search=True)
+    _, hist_gpu, n_gpu = S.sa_nsga2(ev.compute_objectives_and_constraints, 8, 2, **kw)
+    assert n_gpu == 8 + 2 * 2 == ev.evals_done and len(hist_gpu) == 2 and all(len(h) == 8 for h in hist_gpu)
+    for h in hist_gpu:
+        for rec in h:
+            assert 0.0 <= rec["Accuracy"] <= 1.0 and rec["Size_MB"] > 0
+    _, hist_cpu, n_cpu = S.sa_nsga2(_oracle_population_evaluator(cfg, Xtr, ytr, Xva, yva), 8, 2, **kw)
+    assert n_cpu == n_gpu
+    f_gpu = [[[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in h] for h in hist_gpu]
+    f_cpu = [[[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in h] for h in hist_cpu]
+    ref = nsga.shared_reference_point(f_gpu + f_cpu)
+    hv_g, hv_c = nsga.hypervolume(f_gpu[-1], ref), nsga.hypervolume(f_cpu[-1], ref)
+    print(f"memetic bf16: HV gpu {hv_g:.6f} oracle {hv_c:.6f}")
+    assert abs(hv_g - hv_c) <= 0.10 * max(hv_c, 1e-12)
+
+
+def _compare_histories(hist_gpu, hist_cpu):
+    assert len(hist_gpu) == len(hist_cpu)
+    for hg, hc in zip(hist_gpu, hist_cpu):
+        assert len(hg) == len(hc)
+        key = lambda r: tuple(int(r[k]) for k in G.GENE_KEYS)
+        assert sorted(map(key, hg)) == sorted(map(key, hc))                # same genes survive in both searches
+        full = lambda r: (key(r), r["Accuracy"])
+        for rg, rc in zip(sorted(hg, key=full), sorted(hc, key=full)):
+            assert rg["Size_MB"] == rc["Size_MB"]
+            # true evaluations agree to the gate; surrogate PREDICTIONS (non-infill members) are GP outputs fitted on
+            # them and inherit at most that difference amplified by the GP's conditioning: 5e-3
+            assert abs(rg["Accuracy"] - rc["Accuracy"]) <= 5e-3 and abs(rg["FPR"] - rc["FPR"]) <= 5e-3, (rg, rc)
 
 
 def test_population_schema_determinism_and_problem_shim():

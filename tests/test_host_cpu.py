@@ -21,7 +21,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(L, n), n
-    assert L.cmoop_abi_version() == 1
+    assert L.cmoop_abi_version() == 2
 
 
 def test_abi_host_only_closed_forms_match_python():
@@ -119,3 +119,59 @@ def test_compute_mode_reaches_the_abi_struct():
         EvalConfig(compute="fp16").to_struct()
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cmoop.h")).read()
     assert "#define CMOOP_GEMM_BF16X3 2" in hdr and "#define CMOOP_GEMM_BF16 3" in hdr and "int32_t gemm_mode;" in hdr
+
+
+def test_queued_map_without_process_group_is_a_local_longest_first_queue():
+    from cmoop_audio_processing_amd import queued_map
+    seen = []
+
+    def local(pull):
+        out = {}
+        for i in iter(pull, -1):
+            seen.append(i)
+            out[i] = [float(i), 2.0 * i]
+        return out
+    out = queued_map(local, [3.0, 1.0, 2.0, 3.0], 2, "unused")
+    assert seen == [0, 3, 2, 1]                                   # longest first, ties by index
+    assert out.tolist() == [[0, 0], [1, 2], [2, 4], [3, 6]]
+    assert queued_map(lambda pull: {}, [], 3, "unused").shape == (0, 3)
+    import pytest
+    with pytest.raises(Exception):                                # a worker that drops a candidate is an error, not a NaN
+        queued_map(lambda pull: {}, [1.0], 1, "unused")
+
+
+def test_wgrad_slice_count_is_not_monotone_in_the_batch_and_the_abi_reports_it():
+    """the trainer sized its wgrad slab workspace from the FULL batch although a partial last batch
+    can ask for MORE slices (gene (32,3,*,1,*,*) topology A, layer 51x20 32->64 k3: 98 slices at B=64, 109 at B=28..51).
+    The fix sizes for the worst B in 1..batch and clamps; this pins the host heuristic through the C ABI (no GPU)."""
+    import ctypes as C
+    from cmoop_audio_processing_amd import _lib, genes as G
+    L = _lib.lib()
+
+    def slices(B, H, W, Cin, Cout, KS, stride=1):
+        out = C.c_int32()
+        _lib.check(L.cmoop_wgrad_slices(B, H, W, Cin, Cout, KS, stride, C.byref(out)))
+        return out.value
+    full = slices(64, 51, 20, 32, 64, 3)
+    partial = [slices(b, 51, 20, 32, 64, 3) for b in range(1, 65)]
+    assert max(partial) > full, (full, max(partial))             # the non-monotonicity that overflowed the workspace
+    assert all(s >= 1 for s in partial)
+    # every conv/dense layer of every gene: the worst-case need over B is what Net::build_plan now allocates; here
+    # we only check the ABI answers for all of them and that the need is bounded (slab cap: 16M floats + one slice)
+    worst = 0
+    for g in [(16, 3, 0, 3, 4, 0), (32, 5, 0, 2, 2, 0), (64, 5, 0, 3, 1, 0), (64, 3, 0, 1, 4, 0)]:
+        h, w = 101, 40
+        for spec in G.layer_specs(g, 0, 10):
+            if spec["kind"] != "conv" or spec["cin"] == 1:
+                continue
+            if spec["name"].endswith("_skip"):
+                need = max(slices(b, h, w, spec["cin"], spec["cout"], 1, 2) * spec["cout"] * (spec["cin"] + 1) for b in (1, 17, 40, 64))
+            else:
+                if spec["name"].endswith("conv1") and spec["name"].startswith("res"):
+                    pass
+                need = max(slices(b, h, w, spec["cin"], spec["cout"], spec["k"]) * spec["cout"] * (spec["k"] ** 2 * spec["cin"] + 1)
+                           for b in (1, 17, 40, 64))
+            worst = max(worst, need)
+            if spec["name"] in ("conv2",) or spec["name"].endswith("conv2"):
+                h, w = (h + 1) // 2, (w + 1) // 2
+    assert 0 < worst < (1 << 26)
