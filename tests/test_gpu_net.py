@@ -249,7 +249,7 @@ def test_reference_input_shapes_at_the_boundary():
 
 @pytest.mark.parametrize("B", [28, 40, 51])
 def test_wgrad_workspace_partial_batches_advice_r1(B):
-    """gene (32,3,*,1,*,*) topology A at 101x40, batch 64 -- the layer 51x20 32->64 k3 asks for 98
+    """gene (32,3,*,1,*,*) topology A at 101x40, batch 64 -- the block's second conv (51x20, 64->64 k3) asks for 98
     wgrad slices at the full batch but 109 for B in 28..51, which overflowed a workspace sized from the full batch.
     One train step at such a B against the oracle (gradients of every tensor), then a full-batch step on the same
     net (the workspace must serve both)."""
