@@ -102,6 +102,23 @@ def synth_waveforms(n, classes, seed, device, n_samples=16000, chunk=2000, hard=
     return wav, y
 
 
+def usable_cpus():
+    """CPUs this process may really use: min(os.cpu_count, affinity, cgroup quota) -- a GPU box may show 128 cores and
+    grant the job a 16-CPU share; the CPU baseline reports and uses THIS number of threads."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(pop, variant, classes, T, F, n_train, n_val, epochs, X_sample, y_sample, budget_s=15.0):
     """Time the oracle (torch-CPU restatement of the reference path) on this box's host cores
     on a bounded sample: train steps of batch 64 + inference on 64 rows for the cheapest,
@@ -110,7 +127,8 @@ def cpu_baseline(pop, variant, classes, T, F, n_train, n_val, epochs, X_sample, 
     import torch
     from cmoop_audio_processing_amd import genes as G
     from oracle import net as ON
-    cores = torch.get_num_threads()
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
     fl = [G.fwd_flops_per_sample(g, variant, classes, T, F) for g in pop]
     order = np.argsort(fl)
     picks = [int(order[0]), int(order[len(order) // 2]), int(order[-1])]
@@ -275,6 +293,12 @@ def main(argv=None, t_origin=None):
     under_rocprof = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if under_rocprof:
         os.environ["CMOOP_PROFILE_PAIRS"] = "1"
+        try:    # keep the module map next to the profile: a tool-side fault is then attributable from the record alone
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open("/proc/self/maps") as f, open(os.path.join(ROOT, "gpurun_out", f"bench_maps_pid{os.getpid()}.txt"), "w") as g:
+                g.write(f.read())
+        except OSError:
+            pass
     if args.gemm_mode != "fp32":
         os.environ["CMOOP_GEMM_MODE"] = args.gemm_mode      # read once by the library
     peak = PEAK_BY_MODE[args.gemm_mode]                      # the roofline of the arithmetic actually used

@@ -276,6 +276,14 @@ int cmoop_epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* o
     return guard([&] { epoch_permutation(seed, epoch, n, out_host); });
 }
 
+int cmoop_epoch_permutation_device(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out_dev) {
+    return guard([&] {
+        hipStream_t s = lib_stream();
+        launch_epoch_permutation(seed, epoch, n, out_dev, s);
+        CMOOP_HIP(hipStreamSynchronize(s));
+    });
+}
+
 // ---- kernel-level ---------------------------------------------------------------
 
 int cmoop_conv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t H, int32_t W, int32_t Cin,

@@ -598,14 +598,14 @@ void launch_gap_bwd(const float* dY, const float* X, float* dX, int B, int HW, i
 // softmax + Keras-3 sparse_categorical_crossentropy(from_logits=False):
 //   p = softmax(z); pc = clip(p, 1e-7, 1-1e-7); loss = -(log pc_y - log sum_j pc_j)
 // (nsga_penalty.py:377-379 via the TF backend).  One block; rows strided over
-// threads; fixed-order LDS tree for the loss / correct counters.
+// lanes; wavefront (shuffle) reductions for the loss / correct counters.
 // ===========================================================================
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ Z, const int32_t* __restrict__ labels,
                                                          const int32_t* __restrict__ idx, int64_t row0, int B, int C,
                                                          float* __restrict__ dZ, double* __restrict__ acc,
                                                          int32_t* __restrict__ preds) {
-    __shared__ double lsum[256];
-    __shared__ int csum[256];
+    __shared__ double lsum[4];
+    __shared__ int csum[4];
     const int t = threadIdx.x;
     const float lo = 1e-7f, hi = 1.0f - 1e-7f;
     double myloss = 0.0;
@@ -648,16 +648,17 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
             }
         }
     }
-    lsum[t] = myloss;
-    csum[t] = mycorrect;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (t < off) { lsum[t] += lsum[t + off]; csum[t] += csum[t + off]; }
-        __syncthreads();
+    // wavefront reduction (fixed butterfly order: deterministic), then the four wave sums in wave order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        myloss += __shfl_xor(myloss, off, 64);
+        mycorrect += __shfl_xor(mycorrect, off, 64);
     }
+    if ((t & 63) == 0) { lsum[t >> 6] = myloss; csum[t >> 6] = mycorrect; }
+    __syncthreads();
     if (t == 0 && acc) {
-        acc[0] += lsum[0];
-        reinterpret_cast<long long*>(acc)[1] += csum[0];
+        acc[0] += ((lsum[0] + lsum[1]) + lsum[2]) + lsum[3];
+        reinterpret_cast<long long*>(acc)[1] += (csum[0] + csum[1]) + (csum[2] + csum[3]);
     }
 }
 
@@ -687,6 +688,38 @@ void launch_adam(float* w, const float* g, float* m, float* v, int64_t n, float 
                  hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, s, w, g, m, v, n, alpha, c1, c2, eps);
+    CMOOP_HIP(hipGetLastError());
+}
+
+// Epoch shuffle on the device (Keras fit(shuffle=True), nsga_penalty.py:383; seeded here): the permutation that sorts
+// the keys (fmix32(prefix ^ i) << 32 | i), i.e. exactly what the host twin (net.hip epoch_permutation, oracle/rng.py)
+// produces with std::sort -- computed as a rank sort: out[#{j : key_j < key_i}] = i.  O(n^2) compares on LDS tiles
+// (0.6 G for n = 24 000: tens of microseconds chip-wide), no host sort, no H2D copy, no stream stall.
+__global__ __launch_bounds__(256) void epoch_permutation_kernel(uint32_t prefix, int n, int32_t* __restrict__ out) {
+    __shared__ uint32_t hs[1024];
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 256 + t;
+    const uint32_t hi = fmix32(prefix ^ (uint32_t)i);
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 1024) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hs[t + 256 * u] = fmix32(prefix ^ (uint32_t)(j0 + t + 256 * u));
+        __syncthreads();
+        const int lim = min(1024, n - j0);
+        for (int j = 0; j < lim; ++j) {
+            const uint32_t hj = hs[j];
+            rank += (hj < hi || (hj == hi && j0 + j < i)) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    if (i < n) out[rank] = i;
+}
+
+void launch_epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out, hipStream_t s) {
+    CMOOP_REQUIRE(n >= 0 && n <= EPOCH_PERMUTATION_DEVICE_MAX, "device epoch permutation: n too large (use the host twin)");
+    if (n == 0) return;
+    hipLaunchKernelGGL(epoch_permutation_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s,
+                       rng_prefix(seed, STREAM_SHUFFLE, epoch), (int)n, out);
     CMOOP_HIP(hipGetLastError());
 }
 

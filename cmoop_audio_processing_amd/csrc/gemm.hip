@@ -1061,6 +1061,31 @@ __global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __rest
     Wd[i] = W[(((size_t)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
 }
 
+// every conv layer of a net in ONE launch: blockIdx.y = layer (table row), blockIdx.x strides over its elements
+__global__ __launch_bounds__(256) void flip_transpose_all_kernel(const float* __restrict__ params, float* __restrict__ wd_all,
+                                                                 const FlipEntry* __restrict__ table) {
+    const FlipEntry e = table[blockIdx.y];
+    const int64_t n = (int64_t)e.Cout * e.KH * e.KW * e.Cin;
+    const float* W = params + e.w_off;
+    float* Wd = wd_all + e.wd_off;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int co = (int)(i % e.Cout);
+        int64_t r = i / e.Cout;
+        int kw = (int)(r % e.KW); r /= e.KW;
+        int kh = (int)(r % e.KH);
+        int ci = (int)(r / e.KH);
+        Wd[i] = W[(((size_t)co * e.KH + (e.KH - 1 - kh)) * e.KW + (e.KW - 1 - kw)) * e.Cin + ci];
+    }
+}
+
+void launch_flip_transpose_all(const float* params, float* wd_all, const FlipEntry* table_dev, int layers, int64_t max_elems,
+                               hipStream_t s) {
+    if (layers <= 0 || max_elems <= 0) return;
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(max_elems, 256), 1024));
+    hipLaunchKernelGGL(flip_transpose_all_kernel, dim3(gx, (unsigned)layers), dim3(256), 0, s, params, wd_all, table_dev);
+    CMOOP_HIP(hipGetLastError());
+}
+
 void launch_flip_transpose(const float* W, float* Wd, int Cout, int KH, int KW, int Cin, hipStream_t s) {
     int64_t n = (int64_t)Cout * KH * KW * Cin;
     hipLaunchKernelGGL(flip_transpose_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, W, Wd, Cout, KH, KW, Cin);

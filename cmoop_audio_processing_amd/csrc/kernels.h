@@ -67,6 +67,24 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
 void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s, int64_t stride = 0);
 // Wd[ci][KH-1-kh][KW-1-kw][co] = W[co][kh][kw][ci]   (operand of the dgrad implicit GEMM)
 void launch_flip_transpose(const float* W, float* Wd, int Cout, int KH, int KW, int Cin, hipStream_t s);
+// the same for every conv layer of a net in ONE launch per train step (table rows in device memory)
+struct FlipEntry { int64_t w_off, wd_off; int Cout, KH, KW, Cin; };
+void launch_flip_transpose_all(const float* params, float* wd_all, const FlipEntry* table_dev, int layers, int64_t max_elems,
+                               hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// Dense layers of the MLP head (dense.hip): M = batch rows, K = C_in (multiple of 16), N = units (any).
+// One workgroup per 16x16 output tile, operands read straight from global memory in the MFMA lane layout,
+// fixed-order 4-wave reduction: no split-K slabs, no flip-transposed weights, no slice reduction.
+// mode GEMM_BF16 rounds both operands to bf16 (fp32 accumulation); every other mode is exact fp32.
+// ---------------------------------------------------------------------------
+void launch_dense_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int relu,
+                      int dropout, uint32_t drop_prefix, uint32_t drop_thr, float drop_scale, int mode, hipStream_t s);
+// dX[m][k] = sum_n dY[m][n] W[n][k]; mask != null: dX = mask > 0 ? dX * mask_scale : 0 (ReLU / dropout backward of the layer's input)
+void launch_dense_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, const float* mask, float mask_scale,
+                        int mode, hipStream_t s);
+// dW[n][k] = sum_m dY[m][n] X[m][k], dB[n] = sum_m dY[m][n]
+void launch_dense_wgrad(const float* X, const float* dY, float* dW, float* dB, int M, int N, int K, int mode, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // First layer (C_in = 1, K = 9 or 25: too small for MFMA) -- direct conv on the VALU.
@@ -127,6 +145,9 @@ void launch_softmax_ce(const float* Z, const int32_t* labels, const int32_t* idx
                        float* dZ, double* acc, int32_t* preds, hipStream_t s);
 void launch_adam(float* w, const float* g, float* m, float* v, int64_t n, float alpha, float c1, float c2,
                  float eps, hipStream_t s);
+// device twin of epoch_permutation (net.h): out[rank of key_i] = i; n <= EPOCH_PERMUTATION_DEVICE_MAX (O(n^2) rank sort)
+constexpr int64_t EPOCH_PERMUTATION_DEVICE_MAX = 262144;
+void launch_epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out, hipStream_t s);
 void launch_confusion(const int32_t* y_true, const int32_t* y_pred, int64_t n, int C, int force_true_zero,
                       int64_t* cm, hipStream_t s);
 

@@ -49,9 +49,10 @@ struct GemmHook {   // brackets every MFMA GEMM launch (HIP-event sampling)
 // wgrad_ws holds wgrad_ws_floats floats; the slice count is clamped to what fits (never written past)
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
                            size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode = GEMM_DEFAULT);
+// wd_ready: wd_ws already holds the flip-transposed weights (the trainer refreshes all layers in one launch per step)
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
                         float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws = nullptr,
-                        size_t sk_floats = 0, int mode = GEMM_DEFAULT);
+                        size_t sk_floats = 0, int mode = GEMM_DEFAULT, bool wd_ready = false);
 
 // cached device allocations (net.hip): get may return stale contents, free never blocks on other streams
 void* pool_alloc(size_t bytes);
@@ -77,7 +78,7 @@ struct Op {
     int relu = 0, need_dgrad = 1, in_is_relu = 0, dgrad_accumulate = 0, dropout_layer = -1;
     float in_mask_scale = 1.f;
     int gemm_mode = GEMM_FP32;   // arithmetic of this layer's three GEMMs
-    int64_t w_off = 0, b_off = 0;
+    int64_t w_off = 0, b_off = 0, wd_off = -1;   // wd_off: this layer's slice of the flip-transposed copy (dgrad operand)
     int tensor_index = 0;   // canonical index of the kernel tensor (RNG init stream)
     // bn
     int64_t gamma_off = 0, beta_off = 0, mm_off = 0, mv_off = 0;
@@ -132,6 +133,9 @@ class Net : public GemmHook {
     int64_t n_params_ = 0;
     float *params_ = nullptr, *grads_ = nullptr, *adam_m_ = nullptr, *adam_v_ = nullptr, *snap_ = nullptr;
     float *wgrad_ws_ = nullptr, *wd_ws_ = nullptr, *red_ws_ = nullptr, *splitk_ws_ = nullptr;
+    FlipEntry* flip_table_ = nullptr;   // device table of the conv layers whose dgrad needs flip-transposed weights
+    int flip_layers_ = 0;
+    int64_t flip_max_elems_ = 0;
     size_t wgrad_ws_floats_ = 0, wd_ws_floats_ = 0, red_ws_floats_ = 0, splitk_ws_floats_ = 0;
     double* acc_train_ = nullptr;   // [2]: loss sum, correct (int64 bits)
     double* acc_eval_ = nullptr;

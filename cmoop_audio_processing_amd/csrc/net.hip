@@ -339,7 +339,7 @@ void Net::build_plan() {
             allocs_.push_back(p);
             op.arg = static_cast<uint8_t*>(p);
         }
-        if (op.kind == OP_CONV || op.kind == OP_DENSE) {
+        if (op.kind == OP_CONV) {   // (dense layers need no workspace: dense.hip)
             const ConvGeom g = geom_of(op, cfg_.batch);
             // the slice count is NOT monotone in the batch rows (a smaller M can flip the K-tile width and the
             // co-resident workgroup count, so a partial last batch may ask for MORE slices than the full one):
@@ -348,7 +348,7 @@ void Net::build_plan() {
                 const ConvGeom gb = geom_of(op, b);
                 wgrad_ws_floats_ = std::max(wgrad_ws_floats_, (size_t)wgrad_slices(gb) * gb.Cout * (gb.K() + 1));
             }
-            wd_ws_floats_ = std::max(wd_ws_floats_, (size_t)g.Cout * g.K());
+            if (op.need_dgrad) { op.wd_off = (int64_t)wd_ws_floats_; wd_ws_floats_ += (size_t)g.Cout * g.K(); }
             // split-K slabs: forward (train and inference batch) and dgrad (input-shaped output)
             splitk_ws_floats_ = std::max(splitk_ws_floats_, igemm_splitk_workspace(g));
             splitk_ws_floats_ = std::max(splitk_ws_floats_, igemm_splitk_workspace(geom_of(op, Bmax_)));
@@ -373,6 +373,20 @@ void Net::build_plan() {
     }
     wgrad_ws_ = dalloc(wgrad_ws_floats_);
     wd_ws_ = dalloc(wd_ws_floats_);
+    {   // one table row per conv layer with a data gradient: refreshed by ONE flip-transpose launch per train step
+        std::vector<FlipEntry> tab;
+        for (const auto& op : ops_)
+            if (op.kind == OP_CONV && op.wd_off >= 0) {
+                tab.push_back(FlipEntry{op.w_off, op.wd_off, op.Cout, op.KS, op.KS, op.Cin});
+                flip_max_elems_ = std::max<int64_t>(flip_max_elems_, (int64_t)op.Cout * op.KS * op.KS * op.Cin);
+            }
+        flip_layers_ = (int)tab.size();
+        if (flip_layers_) {
+            flip_table_ = reinterpret_cast<FlipEntry*>(dalloc(tab.size() * sizeof(FlipEntry) / sizeof(float) + 4));
+            CMOOP_HIP(hipMemcpyAsync(flip_table_, tab.data(), tab.size() * sizeof(FlipEntry), hipMemcpyHostToDevice, stream_));
+            CMOOP_HIP(hipStreamSynchronize(stream_));   // tab is a local
+        }
+    }
     splitk_ws_ = splitk_ws_floats_ ? dalloc(splitk_ws_floats_) : nullptr;
     red_ws_ = dalloc(red_ws_floats_ + 64);
     acc_train_ = reinterpret_cast<double*>(dalloc(8));
@@ -471,14 +485,15 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
 // `g` is the FORWARD geometry.  mask != null applies the ReLU (and dropout scale) backward of the
 // layer's input in the epilogue; accumulate adds into dX (second consumer of a tensor).
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
-                        float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws, size_t sk_floats, int mode) {
+                        float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws, size_t sk_floats, int mode,
+                        bool wd_ready) {
     const int N = g.Cout;
     if (ilog2_exact(N) < 4) {   // output layer: K_dgrad = classes (10/11/35) -- tiny VALU kernel
         CMOOP_REQUIRE(g.KH == 1 && g.H == 1 && g.W == 1 && !accumulate, "non power-of-two C_out only supported for dense layers");
         launch_dense_dgrad_small(dY, W, dX, g.M(), N, g.K(), mask, mask_scale, s);
         return;
     }
-    launch_flip_transpose(W, wd_ws, N, g.KH, g.KW, g.Cin, s);
+    if (!wd_ready) launch_flip_transpose(W, wd_ws, N, g.KH, g.KW, g.Cin, s);
     ConvGeom gd;
     GemmEpilogue e;
     gd.B = g.B; gd.H = g.OH; gd.W = g.OW; gd.Cin = N; gd.Cout = g.Cin; gd.stride = 1;
@@ -544,19 +559,20 @@ void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool 
             launch_conv1_fwd(X, idx, row0, params_ + op.w_off, params_ + op.b_off, acts_[op.out].data, B, T_, F_, op.Cout,
                              op.KS, op.relu, stream_);
             break;
-        case OP_CONV:
-        case OP_DENSE: {
+        case OP_CONV: {
             GemmEpilogue e;
             e.mode = op.gemm_mode;
             e.bias = params_ + op.b_off;
             e.relu = op.relu;
-            if (train && op.dropout_layer >= 0) {
-                e.dropout = 1;
-                e.drop_prefix = rng_prefix(seed_, STREAM_DROPOUT + (uint32_t)op.dropout_layer, (uint32_t)step_);
-                e.drop_thr = (uint32_t)(cfg_.dropout * 16777216.0);
-                e.drop_scale = (float)(1.0 / (1.0 - cfg_.dropout));
-            }
             run_gemm(0, acts_[op.in].data, params_ + op.w_off, acts_[op.out].data, geom_of(op, B), e);
+            break;
+        }
+        case OP_DENSE: {
+            const bool drop = train && op.dropout_layer >= 0;
+            launch_dense_fwd(acts_[op.in].data, params_ + op.w_off, params_ + op.b_off, acts_[op.out].data, B, op.Cout, op.Cin,
+                             op.relu, drop ? 1 : 0,
+                             drop ? rng_prefix(seed_, STREAM_DROPOUT + (uint32_t)op.dropout_layer, (uint32_t)step_) : 0u,
+                             (uint32_t)(cfg_.dropout * 16777216.0), (float)(1.0 / (1.0 - cfg_.dropout)), op.gemm_mode, stream_);
             break;
         }
         case OP_BN: {
@@ -596,11 +612,21 @@ void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool 
 }
 
 void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B) {
+    // dgrad operands: flip-transposed copies of every conv kernel, one launch for the whole net
+    launch_flip_transpose_all(params_, wd_ws_, flip_table_, flip_layers_, flip_max_elems_, stream_);
     for (int oi = (int)ops_.size() - 1; oi >= 0; --oi) {
         const Op& op = ops_[oi];
         switch (op.kind) {
-        case OP_CONV:
         case OP_DENSE: {
+            const float* dY = acts_[op.out].grad;
+            Act& ia = acts_[op.in];
+            launch_dense_wgrad(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, B, op.Cout, op.Cin, op.gemm_mode, stream_);
+            if (op.need_dgrad)
+                launch_dense_dgrad(dY, params_ + op.w_off, ia.grad, B, op.Cout, op.Cin, op.in_is_relu ? ia.data : nullptr,
+                                   op.in_mask_scale, op.gemm_mode, stream_);
+            break;
+        }
+        case OP_CONV: {
             const ConvGeom g = geom_of(op, B);
             const float* dY = acts_[op.out].grad;
             Act& ia = acts_[op.in];
@@ -609,8 +635,9 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B) {
             // than the overlap wins)
             conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, wgrad_ws_floats_, stream_, this, op.gemm_mode);
             if (op.need_dgrad)
-                conv_backward_data(dY, params_ + op.w_off, ia.grad, g, wd_ws_, op.in_is_relu ? ia.data : nullptr,
-                                   op.in_mask_scale, op.dgrad_accumulate, stream_, this, splitk_ws_, splitk_ws_floats_, op.gemm_mode);
+                conv_backward_data(dY, params_ + op.w_off, ia.grad, g, wd_ws_ + op.wd_off, op.in_is_relu ? ia.data : nullptr,
+                                   op.in_mask_scale, op.dgrad_accumulate, stream_, this, splitk_ws_, splitk_ws_floats_, op.gemm_mode,
+                                   true);
             break;
         }
         case OP_BN: {
@@ -731,20 +758,25 @@ EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Data
     int32_t* d_idx = nullptr;
     int32_t* d_preds = nullptr;
     int64_t* d_cm = nullptr;
-    h_idx = static_cast<int32_t*>(pool_alloc_pinned(ds.n_train * 4));
     d_idx = static_cast<int32_t*>(pool_alloc(ds.n_train * 4));
     d_preds = static_cast<int32_t*>(pool_alloc(ds.n_val * 4));
     d_cm = static_cast<int64_t*>(pool_alloc((size_t)cfg.classes * cfg.classes * 8));
-    auto cleanup = [&]() { hipStreamSynchronize(stream); pool_free_pinned(h_idx); pool_free(d_idx); pool_free(d_preds); pool_free(d_cm); };
+    auto cleanup = [&]() { hipStreamSynchronize(stream); if (h_idx) pool_free_pinned(h_idx); pool_free(d_idx); pool_free(d_preds); pool_free(d_cm); };
     try {
         // Model.fit + EarlyStopping(monitor='val_loss', patience) -- keras/src/callbacks/early_stopping.py (3.6)
         double best = INFINITY, last_val_acc = 0.0, last_val_loss = 0.0;
         int wait = 0;
         bool have_best = false;
         for (int epoch = 0; epoch < cfg.epochs; ++epoch) {
-            if (cfg.shuffle) epoch_permutation(seed, (uint32_t)epoch, ds.n_train, h_idx);
-            else std::iota(h_idx, h_idx + ds.n_train, 0);
-            CMOOP_HIP(hipMemcpyAsync(d_idx, h_idx, ds.n_train * 4, hipMemcpyHostToDevice, stream));
+            if (cfg.shuffle && ds.n_train <= EPOCH_PERMUTATION_DEVICE_MAX) {
+                launch_epoch_permutation(seed, (uint32_t)epoch, ds.n_train, d_idx, stream);   // no host sort, no H2D
+            } else if (cfg.shuffle || epoch == 0) {
+                if (!h_idx) h_idx = static_cast<int32_t*>(pool_alloc_pinned(ds.n_train * 4));
+                if (cfg.shuffle) epoch_permutation(seed, (uint32_t)epoch, ds.n_train, h_idx);
+                else std::iota(h_idx, h_idx + ds.n_train, 0);
+                CMOOP_HIP(hipMemcpyAsync(d_idx, h_idx, ds.n_train * 4, hipMemcpyHostToDevice, stream));
+                CMOOP_HIP(hipStreamSynchronize(stream));   // h_idx is rewritten next epoch
+            }
             for (int64_t s = 0; s < ds.n_train; s += cfg.batch)
                 net.train_step(ds.x_train, ds.y_train, d_idx, s, (int)std::min<int64_t>(cfg.batch, ds.n_train - s));
             double ls; long long corr;

@@ -140,6 +140,8 @@ int cmoop_net_evaluate(cmoop_net* net, const float* x_dev, const int32_t* y_dev,
                        int64_t* correct, int32_t* preds_dev);
 int cmoop_net_train_metrics(cmoop_net* net, double* loss_sum, int64_t* correct, int32_t reset);
 int cmoop_epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out_host);
+/* the same permutation computed on the GPU (what the trainer uses: no host sort / H2D copy per epoch); n <= 262144 */
+int cmoop_epoch_permutation_device(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out_dev);
 
 /* ---- kernel-level entry points (parity tests and the roofline leg of bench.py).
  *      conv: y[B,OH,OW,Cout] = SAME-conv(x[B,H,W,Cin], w[Cout][KS][KS][Cin]) + bias, optional ReLU */

@@ -116,9 +116,13 @@ class OracleNet:
     documented in cmoop_audio_processing_amd/genes.py so weights can be swapped
     with the HIP library for parity tests."""
 
-    def __init__(self, gene: Sequence[int], cfg: OracleConfig, seed: int):
+    def __init__(self, gene: Sequence[int], cfg: OracleConfig, seed: int, dtype: torch.dtype = torch.float32):
+        """dtype=torch.float64 gives the same net evaluated in double precision from the SAME float32 initial weights:
+        the ground truth that tells fp32 summation-order noise (of this oracle and of the HIP kernels alike) from real
+        differences (tests only; the protocol itself is float32, as the reference's)."""
         self.gene = tuple(int(v) for v in gene)
         self.cfg = cfg
+        self.dtype = dtype
         self.seed = int(seed) & 0xFFFFFFFF
         f, k, bn, R, fc, dr = self.gene
         self.use_bn, self.use_dropout = bool(bn), bool(dr)
@@ -134,7 +138,7 @@ class OracleNet:
                 arr = np.ones(shape, np.float32)
             else:
                 arr = np.zeros(shape, np.float32)
-            t = torch.from_numpy(arr.copy())
+            t = torch.from_numpy(arr.copy()).to(dtype)
             if role in ("kernel", "bias", "gamma", "beta"):
                 t.requires_grad_(True)
                 self.trainable.append(name)
@@ -189,14 +193,14 @@ class OracleNet:
         return sum(int(t.numel()) for t in self.T.values())
 
     def get_flat(self) -> np.ndarray:
-        return np.concatenate([self.T[n].detach().numpy().ravel() for n in self.names]).astype(np.float32)
+        return np.concatenate([self.T[n].detach().numpy().ravel() for n in self.names]).astype(np.float32 if self.dtype == torch.float32 else np.float64)
 
     def set_flat(self, flat: np.ndarray) -> None:
         off = 0
         with torch.no_grad():
             for n in self.names:
                 t = self.T[n]
-                t.copy_(torch.from_numpy(np.asarray(flat[off:off + t.numel()], np.float32).reshape(t.shape)))
+                t.copy_(torch.from_numpy(np.asarray(flat[off:off + t.numel()], np.float32).reshape(t.shape)).to(t.dtype))
                 off += t.numel()
         assert off == len(flat)
 
@@ -206,7 +210,7 @@ class OracleNet:
             t = self.T[n]
             g = t.grad if (t.requires_grad and t.grad is not None) else torch.zeros_like(t)
             out.append(g.detach().numpy().ravel())
-        return np.concatenate(out).astype(np.float32)
+        return np.concatenate(out).astype(np.float32 if self.dtype == torch.float32 else np.float64)
 
     # ---- layers --------------------------------------------------------------
     def _bn(self, x, name, train):
@@ -279,7 +283,7 @@ class OracleNet:
             if dr and train:
                 keep = orng.dropout_keep(self.seed, li, self.step, x.shape[0], x.shape[1], self.cfg.dropout)
                 scale = np.float32(1.0 / (1.0 - self.cfg.dropout))
-                x = x * torch.from_numpy(keep.astype(np.float32)) * float(scale)
+                x = x * torch.from_numpy(keep.astype(np.float32)).to(x.dtype) * float(scale)
         z = x @ self.T["output_layer/kernel"].t() + self.T["output_layer/bias"]
         return torch.softmax(z, dim=1)
 
@@ -296,7 +300,7 @@ class OracleNet:
         cfg = self.cfg
         for n in self.trainable:
             self.T[n].grad = None
-        p = self.forward(torch.from_numpy(np.ascontiguousarray(xb, np.float32)), True)
+        p = self.forward(torch.from_numpy(np.ascontiguousarray(xb, np.float32)).to(self.dtype), True)
         y = torch.from_numpy(np.asarray(yb).astype(np.int64).ravel())
         lps = self.loss_per_sample(p, y)
         lps.mean().backward()
@@ -321,7 +325,7 @@ class OracleNet:
         tot, corr, preds = 0.0, 0, []
         yv = np.asarray(y).astype(np.int64).ravel()
         for s in range(0, n, chunk):
-            p = self.forward(torch.from_numpy(np.ascontiguousarray(X[s:s + chunk], np.float32)), False)
+            p = self.forward(torch.from_numpy(np.ascontiguousarray(X[s:s + chunk], np.float32)).to(self.dtype), False)
             yy = torch.from_numpy(yv[s:s + chunk])
             tot += float(self.loss_per_sample(p, yy).double().sum())
             pr = p.argmax(dim=1)
@@ -379,9 +383,10 @@ def fit(net: OracleNet, Xtr, ytr, Xval, yval, max_steps: Optional[int] = None):
     return hist
 
 
-def evaluate_individual(gene, cfg: OracleConfig, Xtr, ytr, Xval, yval, seed: int):
-    """Oracle twin of evaluate_individual -> (accuracy, size_mb, fpr, epochs_run)."""
-    net = OracleNet(gene, cfg, seed)
+def evaluate_individual(gene, cfg: OracleConfig, Xtr, ytr, Xval, yval, seed: int, dtype: torch.dtype = torch.float32):
+    """Oracle twin of evaluate_individual -> (accuracy, size_mb, fpr, epochs_run).  dtype=float64: the same protocol
+    from the same float32 initial weights in double precision (tests: a third sample of the summation-order spread)."""
+    net = OracleNet(gene, cfg, seed, dtype=dtype)
     hist = fit(net, Xtr, ytr, Xval, yval)
     _, acc_eval, preds = net.evaluate(Xval, yval)
     acc = hist["val_accuracy"][-1] if cfg.acc_readout == "last" else acc_eval

@@ -220,6 +220,23 @@ def test_frontend_logmel_and_standardize():
     assert np.abs(feats.cpu().numpy() - ofe.scaler_transform(out.cpu().numpy(), mean, scale)).max() < 1e-5
 
 
+def test_device_epoch_permutation_equals_the_host_and_oracle_twins():
+    """The trainer's per-epoch shuffle is computed on the GPU (rank sort of the counter-RNG keys); it must be the
+    permutation the host twin (C ABI) and the oracle (oracle/rng.py) produce -- bit-exact, all sizes incl. ragged
+    tiles -- and a permutation."""
+    import ctypes as C
+    from cmoop_audio_processing_amd.session import epoch_permutation
+    from oracle import rng as orng
+    for n, seed, epoch in [(1, 0, 0), (5, 1, 3), (255, 2, 1), (256, 3, 0), (1025, 4, 7), (24000, 0, 1), (24000, 12345, 299)]:
+        out = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib().cmoop_epoch_permutation_device(C.c_uint32(seed), C.c_uint32(epoch), C.c_int64(n), _lib.ptr(out)))
+        got = out.cpu().numpy()
+        assert np.array_equal(got, epoch_permutation(seed, epoch, n)), (n, seed, epoch)
+        assert np.array_equal(got, orng.epoch_permutation(seed, epoch, n))
+        assert np.array_equal(np.sort(got), np.arange(n))
+
+
 @pytest.mark.parametrize("mode", ["refit", "train_only", "none"])
 def test_prepare_dataset_modes_vs_oracle_scaler(mode):
     """prepare_dataset's three per-script behaviours against the oracle's StandardScaler restatement:

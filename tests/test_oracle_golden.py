@@ -171,3 +171,39 @@ def test_bf16_oracle_conv_follows_its_stated_definition():
     ON.conv_same(xq, wq, None, 1).backward(q(dy))
     assert torch.equal(x.grad, xq.grad) and torch.equal(w.grad, wq.grad)
     assert torch.allclose(b.grad, dy.sum(dim=(0, 2, 3)))
+
+
+def test_fp32_oracle_trained_bn_net_depends_on_the_summation_order():
+    """Why the end-to-end GPU parity tests gate trained BatchNorm nets on the oracle's OWN spread: the fp32 oracle run
+    twice on identical inputs and seeds, once with torch's default CPU conv algorithm (mkldnn) and once with the native
+    one -- the same arithmetic in a different summation order -- ends in different validation accuracy and even a
+    different early-stopping epoch for a BatchNorm + dropout candidate (~50 optimiser steps are enough), while the
+    candidate without BatchNorm agrees with itself to the last prediction.  No fp32 implementation of this path (Keras
+    on another machine included) reproduces a trained BN net's accuracy to 1e-3; one-step gradients, inference from
+    identical weights and non-BN / confident runs are where the 1e-3 gate is meaningful, and it is enforced there."""
+    import torch
+    from oracle import net as ON
+
+    def make_split(n_train, n_val, T, F, classes, seed, noise, label_noise):
+        rs = np.random.RandomState(seed)
+        f, t = np.arange(F)[None, :], np.arange(T)[:, None]
+        proto = np.stack([np.sin(2 * np.pi * (1 + c % 5) * f / F + 0.7 * c) * np.cos(2 * np.pi * (1 + c // 5) * t / T)
+                          + (c - classes / 2) / classes for c in range(classes)]).astype(np.float32)
+        y = rs.randint(0, classes, size=n_train + n_val).astype(np.int32)
+        X = (proto[y] + noise * rs.randn(n_train + n_val, T, F)).astype(np.float32)
+        flip = rs.rand(n_train + n_val) < label_noise
+        y = np.where(flip, rs.randint(0, classes, size=n_train + n_val), y).astype(np.int32)
+        return X[:n_train], y[:n_train], X[n_train:], y[n_train:]
+
+    Xtr, ytr, Xva, yva = make_split(192, 128, 21, 12, 11, 21, 0.3, 0.25)
+
+    def both(gene):
+        cfg = ON.OracleConfig(variant=1, classes=11, epochs=25, patience=2, batch=32, restore_best=True, acc_readout="evaluate")
+        a = ON.evaluate_individual(gene, cfg, Xtr, ytr, Xva, yva, seed=11)
+        with torch.backends.mkldnn.flags(enabled=False):
+            b = ON.evaluate_individual(gene, cfg, Xtr, ytr, Xva, yva, seed=11)
+        return a, b
+    a, b = both((16, 5, 1, 1, 2, 1))        # BatchNorm + dropout
+    assert abs(a[0] - b[0]) > 1e-3 or a[3] != b[3], (a, b)
+    a, b = both((16, 5, 0, 2, 1, 0))        # no BatchNorm: self-consistent
+    assert abs(a[0] - b[0]) <= 1e-3 and abs(a[2] - b[2]) <= 1e-3 and a[3] == b[3], (a, b)
