@@ -3,6 +3,7 @@
 #include "net.h"
 
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 using namespace cmoop;
@@ -23,16 +24,28 @@ static int guard(F&& f) {
     }
 }
 
+constexpr int MAX_DEVICES = 16;
+
+// one library stream per (calling thread, device): switching devices neither leaks nor reuses the other device's stream
 static hipStream_t lib_stream() {
-    static thread_local hipStream_t s = nullptr;
-    static thread_local int s_dev = -1;
+    static thread_local hipStream_t streams[MAX_DEVICES] = {nullptr};
     int dev = 0;
     CMOOP_HIP(hipGetDevice(&dev));
-    if (!s || s_dev != dev) {
-        CMOOP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        s_dev = dev;
-    }
-    return s;
+    CMOOP_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device index out of range");
+    if (!streams[dev]) CMOOP_HIP(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
+    return streams[dev];
+}
+
+// front-end tables (twiddles / window / sparse mel weights): one set per device, created once under a lock
+static const FrontendTables* frontend_tables_for_current_device() {
+    static std::mutex mu;
+    static FrontendTables* tables[MAX_DEVICES] = {nullptr};
+    int dev = 0;
+    CMOOP_HIP(hipGetDevice(&dev));
+    CMOOP_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device index out of range");
+    std::lock_guard<std::mutex> l(mu);
+    if (!tables[dev]) tables[dev] = frontend_tables_create(FrontendCfg());
+    return tables[dev];
 }
 
 static NetConfig to_cfg(const cmoop_config* c) {
@@ -157,11 +170,7 @@ int cmoop_calculate_fpr(const int32_t* y_true, const int32_t* y_pred, int64_t n,
 // ---- front end ---------------------------------------------------------------
 int cmoop_logmel(const float* wav_dev, int64_t n_clips, int32_t n_samples, float* out_dev) {
     return guard([&] {
-        static FrontendTables* tables = nullptr;
-        static int tables_dev = -1;
-        int dev = 0;
-        CMOOP_HIP(hipGetDevice(&dev));
-        if (!tables || tables_dev != dev) { tables = frontend_tables_create(FrontendCfg()); tables_dev = dev; }
+        const FrontendTables* tables = frontend_tables_for_current_device();
         CMOOP_REQUIRE(n_samples >= 160, "clip shorter than one hop");
         hipStream_t s = lib_stream();
         launch_logmel(wav_dev, n_clips, n_samples, out_dev, tables, s);

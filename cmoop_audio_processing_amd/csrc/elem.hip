@@ -536,6 +536,140 @@ void launch_maxpool_bwd(const float* dY, const uint8_t* arg, const float* Y, flo
     CMOOP_HIP(hipGetLastError());
 }
 
+// ===========================================================================
+// BatchNorm-apply (+ReLU) + MaxPool 2x2 SAME in one pass, and its backward twins: the normalised full-resolution
+// tensor and its gradient are never written.  Arithmetic and tie rules are those of scale_shift_kernel followed by
+// maxpool_fwd_kernel (bit-identical results); backward: dY_full[b,ih,iw,c] = (arg[b,oh,ow,c] == pos) ? g[b,oh,ow,c] : 0
+// is formed on the fly where bn_bwd_reduce / bn_bwd_apply would have read the materialised tensor.
+// ===========================================================================
+__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const float* __restrict__ X, float* __restrict__ Y,
+                                                          uint8_t* __restrict__ arg, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int B, int H, int W, int C,
+                                                          int OH, int OW, int relu) {
+    const int C4 = C >> 2;
+    const int64_t n = (int64_t)B * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int ow = (int)(p % OW); p /= OW;
+        const int oh = (int)(p % OH);
+        const int b = (int)(p / OH);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * c4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
+        f32x4 best;
+        uchar4 a = {0, 0, 0, 0};
+        bool first = true;
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            const int ih = 2 * oh + (pos >> 1), iw = 2 * ow + (pos & 1);
+            if (ih >= H || iw >= W) continue;
+            const f32x4 x = *reinterpret_cast<const f32x4*>(X + ((size_t)(b * H + ih) * W + iw) * C + 4 * c4);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = x[j] * sc[j] + sh[j];
+                v[j] = relu ? fmaxf(t, 0.f) : t;
+            }
+            if (first) { best = v; first = false; continue; }
+            if (v[0] > best[0]) { best[0] = v[0]; a.x = pos; }
+            if (v[1] > best[1]) { best[1] = v[1]; a.y = pos; }
+            if (v[2] > best[2]) { best[2] = v[2]; a.z = pos; }
+            if (v[3] > best[3]) { best[3] = v[3]; a.w = pos; }
+        }
+        *reinterpret_cast<f32x4*>(Y + i * 4) = best;
+        *reinterpret_cast<uchar4*>(arg + i * 4) = a;
+    }
+}
+
+void launch_bn_pool_fwd(const float* X, float* Y, uint8_t* arg, const float* scale, const float* shift, int B, int H, int W,
+                        int C, int relu, hipStream_t s) {
+    CMOOP_REQUIRE(C % 4 == 0, "bn_pool: C % 4");
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const int64_t n = (int64_t)B * OH * OW * (C / 4);
+    if (n == 0) return;
+    hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, s, X, Y, arg, scale, shift, B, H, W, C, OH, OW, relu);
+    CMOOP_HIP(hipGetLastError());
+}
+
+// gradient of the (never materialised) BN output at full-resolution row r = (b, ih, iw), channels c..c+3
+struct PooledGrad {
+    const float* g; const uint8_t* arg;
+    int H, W, OH, OW, C;
+    __device__ __forceinline__ f32x4 at(int64_t row, int c) const {
+        const int iw = (int)(row % W);
+        const int64_t t = row / W;
+        const int ih = (int)(t % H), b = (int)(t / H);
+        const size_t o = (((size_t)b * OH + (ih >> 1)) * OW + (iw >> 1)) * C + c;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o);
+        const uchar4 a = *reinterpret_cast<const uchar4*>(arg + o);
+        const int pos = ((ih & 1) << 1) | (iw & 1);
+        return f32x4{a.x == pos ? gv[0] : 0.f, a.y == pos ? gv[1] : 0.f, a.z == pos ? gv[2] : 0.f, a.w == pos ? gv[3] : 0.f};
+    }
+};
+
+struct BnBwdPooledOp {   // (sum dy, sum dy * xhat) with dy scattered from the pooled gradient
+    PooledGrad pg; const float* X; const float* mean; const float* invstd;
+    __device__ void operator()(size_t off, int c, f32x4& s0, f32x4& s1) const {
+        const f32x4 dy = pg.at((int64_t)(off / pg.C), c);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(X + off);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        s0 += dy;
+        s1 += dy * ((x - mu) * is);
+    }
+};
+
+void launch_bn_pool_bwd_reduce(const float* g_pooled, const uint8_t* arg, const float* X, const float* mean, const float* invstd,
+                               float* P, int B, int H, int W, int C, int blocks, hipStream_t s) {
+    const int64_t M = (int64_t)B * H * W;
+    check_colreduce(M, C);
+    BnBwdPooledOp op{PooledGrad{g_pooled, arg, H, W, (H + 1) / 2, (W + 1) / 2, C}, X, mean, invstd};
+    hipLaunchKernelGGL((colreduce_kernel<BnBwdPooledOp>), dim3(blocks), dim3(256), 0, s, op, P, M, C, cdiv64(M, blocks));
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(PooledGrad pg, const float* __restrict__ X,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ sums, float* __restrict__ dX,
+                                                                int64_t n4, int C, float invM, int mask_x_pos) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 dy = pg.at((i * 4) / C, c);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(X + i * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + c);
+        const f32x4 s2 = *reinterpret_cast<const f32x4*>(sums + C + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (x[j] - mu[j]) * is[j];
+            float v = ga[j] * is[j] * (dy[j] - s1[j] * invM - xh * (s2[j] * invM));
+            if (mask_x_pos && !(x[j] > 0.f)) v = 0.f;
+            o[j] = v;
+        }
+        *reinterpret_cast<f32x4*>(dX + i * 4) = o;
+    }
+}
+
+void launch_bn_pool_bwd_apply(const float* g_pooled, const uint8_t* arg, const float* X, const float* mean, const float* invstd,
+                              const float* gamma, const float* P, int blocks, float* dX, float* dgamma, float* dbeta, int B,
+                              int H, int W, int C, int mask_x_pos, hipStream_t s) {
+    const int64_t M = (int64_t)B * H * W;
+    float* sums = const_cast<float*>(P) + (size_t)blocks * 2 * C;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, P, blocks, C, sums, dgamma, dbeta);
+    CMOOP_HIP(hipGetLastError());
+    const int64_t n4 = M * C / 4;
+    if (n4 == 0) return;
+    PooledGrad pg{g_pooled, arg, H, W, (H + 1) / 2, (W + 1) / 2, C};
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, pg, X, mean, invstd, gamma, sums, dX, n4, C,
+                       (float)(1.0 / (double)M), mask_x_pos);
+    CMOOP_HIP(hipGetLastError());
+}
+
 __global__ __launch_bounds__(256) void add_relu_kernel(const float* __restrict__ A, const float* __restrict__ Bt,
                                                        float* __restrict__ Y, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {

@@ -77,6 +77,7 @@ struct GeomDev {
     const float* zeros;    // 16 zero floats: predicated-off lanes load from here (branch-free gathers)
 };
 struct EpiDev {
+    float* stats;          // non-null: per-M-tile column partials (sum v, sum v^2) of the stored values, [tiles][2][N] (BatchNorm batch statistics)
     const float* bias;
     const float* mask;
     float mask_scale;
@@ -389,6 +390,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             }
         return;
     }
+    float csum[CT], csq[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { csum[ct] = 0.f; csq[ct] = 0.f; }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -418,7 +422,34 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
                 if (e.mask) v = (e.mask[off] > 0.f) ? v * e.mask_scale : 0.f;
                 if (e.accumulate) v += Y[off];
                 Y[off] = v;
+                csum[ct] += v;
+                csq[ct] += v * v;
             }
+        }
+    }
+    if (e.stats) {
+        // BatchNorm batch statistics ride along: column sums over this tile's rows in a fixed order (lane's rows ->
+        // the four row groups of the wave by shuffle -> the WM waves through LDS), one partial per M tile
+        float* red = PLANES ? reinterpret_cast<float*>(&Ah[0][0]) : &As[0][0];   // free after the K loop's last barrier
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            csum[ct] += __shfl_xor(csum[ct], 16, 64);
+            csq[ct] += __shfl_xor(csq[ct], 16, 64);
+            csum[ct] += __shfl_xor(csum[ct], 32, 64);
+            csq[ct] += __shfl_xor(csq[ct], 32, 64);
+            if (q == 0) {
+                const int c = wcol + ct * 16 + lr;
+                red[((wave / WN) * BN + c) * 2] = csum[ct];
+                red[((wave / WN) * BN + c) * 2 + 1] = csq[ct];
+            }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < N) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { a += red[(w * BN + t) * 2]; b += red[(w * BN + t) * 2 + 1]; }
+            e.stats[((size_t)mtile * 2) * N + n0 + t] = a;
+            e.stats[((size_t)mtile * 2 + 1) * N + n0 + t] = b;
         }
     }
 }
@@ -562,7 +593,8 @@ size_t igemm_splitk_workspace(const ConvGeom& g) {
 }
 
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& cg, const GemmEpilogue& ep,
-                     hipStream_t s, const GemmTiming* tm, float* splitk_ws, size_t splitk_ws_floats) {
+                     hipStream_t s, const GemmTiming* tm, float* splitk_ws, size_t splitk_ws_floats, int* stats_blocks) {
+    if (stats_blocks) *stats_blocks = 0;
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
     EpiDev e;
@@ -577,6 +609,10 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     const bool bk32 = mode != GEMM_FP32 || (g.Cin % 32 == 0);
     int bm, bn, splits;
     pick_tile(g.M, g.Cout, g.K, bk32 ? 32 : 16, splitk_ws ? splitk_ws_floats : 0, &bm, &bn, &splits);
+    // fused column statistics only on un-split launches (split-K partials are raw sums; the caller falls back to the
+    // stand-alone reduction there: those are the small 13x5 / 26x10 layers)
+    e.stats = (ep.stats && stats_blocks && splits == 1 && ep.out_stride == 1 && !ep.accumulate) ? ep.stats : nullptr;
+    if (e.stats) *stats_blocks = cdiv(g.M, bm);
     // many-wave grids of 128x64 tiles run 3-4 % faster with 16-deep K chunks (half the LDS, 4-5 workgroups
     // per CU instead of 2); single-wave grids prefer the 32-deep chunk (half the barriers)
     const bool bk32_tile = mode != GEMM_FP32 ||

@@ -37,6 +37,9 @@ struct GemmEpilogue {
     int dropout = 0;               // inverted dropout keyed by fmix32(drop_prefix ^ (row*N+col))
     uint32_t drop_prefix = 0, drop_thr = 0;
     float drop_scale = 1.f;
+    // optional: column partials (sum, sum of squares) of the stored output, one per M tile: [tiles][2][Cout] floats --
+    // the BatchNorm batch statistics computed in the producing conv's epilogue.  Needs room for cdiv(M, 64) tiles.
+    float* stats = nullptr;
 };
 
 // Y[m][n] = sum_k im2col(X)[m][k] * Wt[n][k]  (+ epilogue).  Cin must be a power of two >= 16.
@@ -49,9 +52,10 @@ struct GemmTiming {
 };
 // returns the instantiation code mode*1e8 + BM*100000 + BN*100 + BK of the kernel that was launched
 // splitk_ws (optional, >= igemm_splitk_workspace(g) floats): lets under-filled grids split the K axis
+// stats_blocks (with e.stats): receives the number of M-tile partials written, 0 when the launch was split-K (no fused statistics)
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& g,
                      const GemmEpilogue& e, hipStream_t s, const GemmTiming* tm = nullptr,
-                     float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
+                     float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, int* stats_blocks = nullptr);
 size_t igemm_splitk_workspace(const ConvGeom& g);
 
 // dWt[n][k] = sum_m dY[m][n] * im2col(X)[m][k], split over S row-slices into P[S][N][K].
@@ -136,6 +140,15 @@ void launch_colsum_finalize(const float* P, int blocks, int C, float* out, hipSt
 void launch_maxpool_fwd(const float* X, float* Y, uint8_t* arg, int B, int H, int W, int C, hipStream_t s);
 void launch_maxpool_bwd(const float* dY, const uint8_t* arg, const float* Y, float* dX, int B, int H, int W, int C,
                         int mask_y_pos, hipStream_t s);
+// BatchNorm-apply (+ReLU) + MaxPool in one pass and the matching backward (the full-resolution normalised tensor and
+// its gradient are never materialised); results bit-identical to scale_shift + maxpool_fwd / maxpool_bwd + bn_bwd_*.
+void launch_bn_pool_fwd(const float* X, float* Y, uint8_t* arg, const float* scale, const float* shift, int B, int H, int W,
+                        int C, int relu, hipStream_t s);
+void launch_bn_pool_bwd_reduce(const float* g_pooled, const uint8_t* arg, const float* X, const float* mean, const float* invstd,
+                               float* P, int B, int H, int W, int C, int blocks, hipStream_t s);
+void launch_bn_pool_bwd_apply(const float* g_pooled, const uint8_t* arg, const float* X, const float* mean, const float* invstd,
+                              const float* gamma, const float* P, int blocks, float* dX, float* dgamma, float* dbeta, int B,
+                              int H, int W, int C, int mask_x_pos, hipStream_t s);
 void launch_add_relu(const float* A, const float* Bt, float* Y, int64_t n, hipStream_t s);
 void launch_gap_fwd(const float* X, float* Y, int B, int HW, int C, hipStream_t s);
 void launch_gap_bwd(const float* dY, const float* X, float* dX, int B, int HW, int C, hipStream_t s);

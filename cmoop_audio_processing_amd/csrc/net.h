@@ -65,6 +65,7 @@ struct Act {
     float* grad = nullptr;
     int H = 0, W = 0, C = 0;
     bool own_grad = false;
+    bool virt = false;         // never materialised (BatchNorm output consumed by a fused max-pool)
     size_t per_sample() const { return (size_t)H * W * C; }
 };
 
@@ -83,10 +84,13 @@ struct Op {
     // bn
     int64_t gamma_off = 0, beta_off = 0, mm_off = 0, mv_off = 0;
     int relu_after = 0, mask_in_pos = 0;
+    int fuse_pool = 0;         // bn: the next op is the max-pool of this BN's output -> one fused kernel, output never materialised
+    int feeds_bn = 0;          // conv: the next op is the BatchNorm of this conv's output (statistics fused into the epilogue)
     float* bn_buf = nullptr;   // mean | invstd | scale | shift, each [C]
     // pool
     uint8_t* arg = nullptr;
     int mask_y_pos = 0;
+    int fused_into_bn = 0;     // pool: executed inside the preceding BatchNorm's fused kernels
 };
 
 class Net : public GemmHook {
@@ -119,7 +123,7 @@ class Net : public GemmHook {
     void forward(const float* X, const int32_t* idx, int64_t row0, int B, bool train);
     void backward(const float* X, const int32_t* idx, int64_t row0, int B);
     ConvGeom geom_of(const Op& op, int B) const;
-    void run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e);
+    void run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e, int* stats_blocks = nullptr);
     float* dalloc(size_t floats);
 
     int32_t gene_[6];
@@ -142,6 +146,7 @@ class Net : public GemmHook {
     int logits_ = -1;
     long long step_ = 0, iterations_ = 0;
     bool profiling_now_ = false, hook_live_ = false;
+    int fused_stats_blocks_ = 0;   // > 0: the conv just launched left this many BatchNorm statistic partials in red_ws_
     struct EvPair { GemmTiming t; double flops; int cls, code; };
     std::vector<EvPair> ev_pool_;
     size_t ev_used_ = 0;

@@ -218,6 +218,7 @@ void Net::build_plan() {
         return op.out;
     };
     auto add_bn = [&](int in, int relu_after, int mask_in_pos) {
+        if (!ops_.empty() && ops_.back().kind == OP_CONV && ops_.back().out == in) ops_.back().feeds_bn = 1;
         Op op; op.kind = OP_BN; op.in = in; op.relu_after = relu_after; op.mask_in_pos = mask_in_pos;
         const Act ia = acts_[in];
         op.Cout = ia.C;
@@ -232,6 +233,11 @@ void Net::build_plan() {
     };
     auto add_pool = [&](int in, int mask_y_pos) {
         Op op; op.kind = OP_POOL; op.in = in; op.mask_y_pos = mask_y_pos;
+        if (!ops_.empty() && ops_.back().kind == OP_BN && ops_.back().out == in && !mask_y_pos) {
+            ops_.back().fuse_pool = 1;      // BN-apply (+ReLU) + pool in one pass; the BN output is never written
+            op.fused_into_bn = 1;
+            acts_[in].virt = true;
+        }
         const Act ia = acts_[in];
         op.out = new_act((ia.H + 1) / 2, (ia.W + 1) / 2, ia.C);
         ops_.push_back(op);
@@ -294,9 +300,11 @@ void Net::build_plan() {
     CMOOP_REQUIRE(n_params_ == param_count(gene_, cfg_.variant, cfg_.classes), "plan / closed-form parameter count mismatch");
 
     // ---- activations ------------------------------------------------------
-    for (size_t i = 1; i < acts_.size(); ++i) acts_[i].data = dalloc((size_t)Bmax_ * acts_[i].per_sample());
+    for (size_t i = 1; i < acts_.size(); ++i)
+        if (!acts_[i].virt) acts_[i].data = dalloc((size_t)Bmax_ * acts_[i].per_sample());
     // gradients: residual add aliases its operands' grads with its output's
     for (size_t i = 1; i < acts_.size(); ++i) {
+        if (acts_[i].virt) continue;
         acts_[i].grad = dalloc((size_t)cfg_.batch * acts_[i].per_sample());
         acts_[i].own_grad = true;
     }
@@ -368,7 +376,9 @@ void Net::build_plan() {
         }
         if (op.kind == OP_BN) {
             const int64_t M = (int64_t)Bmax_ * acts_[op.in].H * acts_[op.in].W;
-            red_ws_floats_ = std::max(red_ws_floats_, (size_t)colreduce_blocks(M, op.Cout) * 2 * op.Cout + 2 * op.Cout);
+            // stand-alone reduction partials, or one partial per 64-row tile of the producing conv (fused statistics)
+            const size_t blocks = std::max<size_t>((size_t)colreduce_blocks(M, op.Cout), (size_t)cdiv64(M, 64));
+            red_ws_floats_ = std::max(red_ws_floats_, blocks * 2 * op.Cout + 2 * op.Cout);
         }
     }
     wgrad_ws_ = dalloc(wgrad_ws_floats_);
@@ -514,9 +524,9 @@ void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGe
     if (hook) hook->end(code);
 }
 
-void Net::run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e) {
+void Net::run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e, int* stats_blocks) {
     const GemmTiming* tm = begin(cls, 2.0 * g.M() * (double)g.Cout * g.K());
-    end(launch_igemm_fwd(X, Wt, Y, g, e, stream_, tm, splitk_ws_, splitk_ws_floats_));
+    end(launch_igemm_fwd(X, Wt, Y, g, e, stream_, tm, splitk_ws_, splitk_ws_floats_, stats_blocks));
 }
 
 void Net::drain_profile() {
@@ -553,7 +563,8 @@ void Net::drain_profile() {
 // ---------------------------------------------------------------------------
 void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool train) {
     CMOOP_REQUIRE(B >= 1 && B <= Bmax_, "batch larger than the net was planned for");
-    for (const Op& op : ops_) {
+    for (size_t oi = 0; oi < ops_.size(); ++oi) {
+        const Op& op = ops_[oi];
         switch (op.kind) {
         case OP_CONV1:
             launch_conv1_fwd(X, idx, row0, params_ + op.w_off, params_ + op.b_off, acts_[op.out].data, B, T_, F_, op.Cout,
@@ -564,7 +575,10 @@ void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool 
             e.mode = op.gemm_mode;
             e.bias = params_ + op.b_off;
             e.relu = op.relu;
-            run_gemm(0, acts_[op.in].data, params_ + op.w_off, acts_[op.out].data, geom_of(op, B), e);
+            fused_stats_blocks_ = 0;
+            if (train && op.feeds_bn) e.stats = red_ws_;    // BatchNorm batch statistics in the conv epilogue
+            run_gemm(0, acts_[op.in].data, params_ + op.w_off, acts_[op.out].data, geom_of(op, B), e,
+                     e.stats ? &fused_stats_blocks_ : nullptr);
             break;
         }
         case OP_DENSE: {
@@ -581,8 +595,12 @@ void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool 
             const int C = op.Cout;
             float *mean = op.bn_buf, *invstd = mean + C, *scale = invstd + C, *shift = scale + C;
             if (train) {
-                const int nb = colreduce_blocks(M, C);
-                launch_colstats(ia.data, red_ws_, M, C, nb, stream_);
+                int nb = fused_stats_blocks_;              // partials left by the producing conv's epilogue, if any
+                fused_stats_blocks_ = 0;
+                if (nb == 0) {
+                    nb = colreduce_blocks(M, C);
+                    launch_colstats(ia.data, red_ws_, M, C, nb, stream_);
+                }
                 launch_bn_finalize(red_ws_, nb, M, C, params_ + op.gamma_off, params_ + op.beta_off, params_ + op.mm_off,
                                    params_ + op.mv_off, mean, invstd, scale, shift, (float)cfg_.bn_eps, (float)cfg_.bn_momentum,
                                    (float)(1.0 - cfg_.bn_momentum), stream_);
@@ -590,10 +608,16 @@ void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool 
                 launch_bn_eval_prepare(params_ + op.gamma_off, params_ + op.beta_off, params_ + op.mm_off,
                                        params_ + op.mv_off, scale, shift, C, (float)cfg_.bn_eps, stream_);
             }
-            launch_scale_shift(ia.data, acts_[op.out].data, scale, shift, M, C, op.relu_after, stream_);
+            if (op.fuse_pool) {
+                const Op& pool = ops_[oi + 1];
+                launch_bn_pool_fwd(ia.data, acts_[pool.out].data, pool.arg, scale, shift, B, ia.H, ia.W, C, op.relu_after, stream_);
+            } else {
+                launch_scale_shift(ia.data, acts_[op.out].data, scale, shift, M, C, op.relu_after, stream_);
+            }
             break;
         }
         case OP_POOL: {
+            if (op.fused_into_bn) break;
             const Act& ia = acts_[op.in];
             launch_maxpool_fwd(ia.data, acts_[op.out].data, op.arg, B, ia.H, ia.W, ia.C, stream_);
             break;
@@ -646,12 +670,20 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B) {
             const int C = op.Cout;
             float *mean = op.bn_buf, *invstd = mean + C;
             const int nb = colreduce_blocks(M, C);
+            if (op.fuse_pool) {   // the pool's backward is folded in: dY is scattered from the pooled gradient on the fly
+                const Op& pool = ops_[oi + 1];
+                launch_bn_pool_bwd_reduce(acts_[pool.out].grad, pool.arg, ia.data, mean, invstd, red_ws_, B, ia.H, ia.W, C, nb, stream_);
+                launch_bn_pool_bwd_apply(acts_[pool.out].grad, pool.arg, ia.data, mean, invstd, params_ + op.gamma_off, red_ws_, nb,
+                                         ia.grad, grads_ + op.gamma_off, grads_ + op.beta_off, B, ia.H, ia.W, C, op.mask_in_pos, stream_);
+                break;
+            }
             launch_bn_bwd_reduce(acts_[op.out].grad, ia.data, mean, invstd, red_ws_, M, C, nb, stream_);
             launch_bn_bwd_apply(acts_[op.out].grad, ia.data, mean, invstd, params_ + op.gamma_off, red_ws_, nb, ia.grad,
                                 grads_ + op.gamma_off, grads_ + op.beta_off, M, C, op.mask_in_pos, stream_);
             break;
         }
         case OP_POOL: {
+            if (op.fused_into_bn) break;
             const Act& ia = acts_[op.in];
             launch_maxpool_bwd(acts_[op.out].grad, op.arg, acts_[op.out].data, ia.grad, B, ia.H, ia.W, ia.C, op.mask_y_pos,
                                stream_);
