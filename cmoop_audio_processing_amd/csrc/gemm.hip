@@ -158,6 +158,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
                                                         float* __restrict__ slab, int chunks_per_split) {
     static_assert(MODE == GEMM_FP32 || MODE == GEMM_BF16X3 || MODE == GEMM_BF16, "unknown GEMM mode");
     constexpr bool PLANES = MODE != GEMM_FP32;
+    constexpr bool PIPE = false;   // software-pipelined main loop (see below): measured, no gain (it halves the global-load landing time)
+    constexpr bool DIST2 = !PLANES && BM <= 64;   // two-chunk-deep global prefetch (two register sets); on 128-row tiles it costs the second workgroup per CU (measured 104 vs 124 TFLOP/s)
     constexpr int NP = MODE == GEMM_BF16X3 ? 3 : 1;
     constexpr int WN = 4 / WM;
     constexpr int LDK = BK + 8;    // pitch = 2 (mod 4) sixteen-byte slots: conflict-free ds_read_b128 fragments (16-lane groups, 64 banks)
@@ -206,8 +208,56 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     // two register sets: the loads of chunk c+2 are issued before chunk c is computed and are
     // written to LDS only after chunk c+1's compute, so a global-load round trip has two MFMA
     // phases to land (the 64-row tiles of the deep layers have only ~1k MFMA cycles per phase)
-    f32x4 ra0[APASS], rb0[BPASS], ra1[(BM <= 64 && !PLANES) ? APASS : 1], rb1[(BM <= 64 && !PLANES) ? BPASS : 1];
-    auto load_chunk = [&](int c, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+    f32x4 ra0[APASS], rb0[BPASS], ra1[DIST2 ? APASS : 1], rb1[DIST2 ? BPASS : 1];
+    // ---- fast operand loader (a K chunk lies inside ONE filter tap: Cin % BK == 0) -----------------------------------
+    // Every non-MFMA vector instruction of a wave takes issue cycles from the matrix pipe it shares with its SIMD
+    // partner (measured: the un-tuned loader's ~90 VALU per chunk cost 12-15 % of the kernel), so the per-chunk
+    // address work is moved off the VALU: buffer loads with a wave-uniform descriptor, a per-row byte offset computed
+    // ONCE (voffset), the chunk's tap / channel offset on the scalar unit (soffset), and SAME-padding handled by a
+    // precomputed per-row bitmask of invalid taps that turns the voffset out of range (the hardware range check then
+    // returns zeros): 2 VALU per A load, 0 per B load.
+    const bool fast = (g.Cin & (BK - 1)) == 0 && g.KH * g.KW <= 32;
+    const uint32_t x_bias = (uint32_t)((g.pad_t * g.W + g.pad_l) << g.cshift);          // floats: makes every row offset >= 0
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X) - x_bias, 0, (int)(((uint32_t)g.B * g.H * g.W << g.cshift) + x_bias) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, g.Cout * g.K * 4, 0x00020000);
+    uint32_t a_voff[APASS], a_inv[APASS], b_voff[BPASS];
+    if (fast) {
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            a_voff[p] = ((uint32_t)((a_base[p] + a_ih0[p] * g.W + a_iw0[p]) << g.cshift) + x_bias + 4 * kq) * 4u;
+            // valid kh / kw form contiguous ranges: [max(0,-ih0), min(KH, H-ih0)) x [max(0,-iw0), min(KW, W-iw0))
+            const int hlo = max(0, -a_ih0[p]), hhi = min(g.KH, g.H - a_ih0[p]);
+            const int wlo = max(0, -a_iw0[p]), whi = min(g.KW, g.W - a_iw0[p]);
+            const uint32_t wmask = (whi > wlo) ? (((1u << whi) - 1u) & ~((1u << wlo) - 1u)) : 0u;
+            uint32_t okm = 0;
+            for (int kh = 0; kh < g.KH; ++kh)
+                if (kh >= hlo && kh < hhi) okm |= wmask << (kh * g.KW);
+            a_inv[p] = a_ok[p] ? ~okm : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            const int nl = lrow + p * RPP, n = n0 + nl;
+            b_voff[p] = (nl < BN && n < g.Cout) ? (uint32_t)(n * g.K + 4 * kq) * 4u : 0xFFFFFFF0u;
+        }
+    }
+    auto load_chunk_fast = [&](int c, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+        // wave-uniform: tap and first channel of the chunk, as a byte offset for the scalar soffset operand
+        const int k0 = c * BK;
+        const int tap = k0 >> g.cshift, ci0 = k0 & (g.Cin - 1);
+        const int kh = (tap * g.rcp_kw) >> 16, kw = tap - kh * g.KW;
+        const int a_soff = ((((kh * g.W + kw) << g.cshift) + ci0) * 4);
+        const int b_soff = k0 * 4;
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            const uint32_t dead = (uint32_t)__builtin_amdgcn_sbfe((int)a_inv[p], tap, 1);     // -1 when this tap is padding for the row
+            ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(a_voff[p] | dead), a_soff, 0));
+        }
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p)
+            rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)b_voff[p], b_soff, 0));
+    };
+    auto load_chunk_slow = [&](int c, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
         const int kidx = c * BK + 4 * kq;
         const bool kok = kidx < g.K;
         const int tap = kidx >> g.cshift, ci = kidx & (g.Cin - 1);
@@ -226,6 +276,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             const float* src = (nl < BN && n < g.Cout && kok) ? Wt + (size_t)n * g.K + kidx : g.zeros;
             rb[p] = *reinterpret_cast<const f32x4*>(src);
         }
+    };
+    auto load_chunk = [&](int c, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+        if (fast) load_chunk_fast(c, ra, rb);
+        else load_chunk_slow(c, ra, rb);
     };
     auto store_chunk = [&](int buf, const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
 #pragma unroll
@@ -339,8 +393,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             compute(0);
             __syncthreads();
         }
-    } else if constexpr (BM <= 64) {
-        // distance-2 prefetch (two register sets) for the small tiles of the deep layers
+    } else if constexpr (DIST2) {
+        // distance-2 prefetch (two register sets): a global-load round trip gets two MFMA phases to land
         load_chunk(cbeg, ra0, rb0);
         store_chunk(0, ra0, rb0);
         if (cbeg + 1 < nchunks) load_chunk(cbeg + 1, ra1, rb1);
@@ -358,6 +412,50 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             if (c + 2 < nchunks) store_chunk(0, ra0, rb0);
             __syncthreads();
         }
+    } else if constexpr (BK == 32 && PIPE) {
+        // Software-pipelined 128-row tiles: the fragments of 16-k group g+1 are read from LDS while the MFMAs of group
+        // g issue (two fragment register sets), and the barrier sits BETWEEN the two groups of a chunk, so every
+        // barrier release is followed by a full MFMA burst that covers the next chunk's first fragment reads and the
+        // address arithmetic of the next global loads.  MEASURED, NOT ENABLED (PIPE = false): 120-122 vs 123-125 TFLOP/s
+        // on 128->128 k5 -- it halves the time the global loads have to land, and the LDS latencies it hides were
+        // already covered by the partner wave; asymmetric burst priorities between the co-resident workgroups
+        // (to break a suspected lockstep) changed nothing either.
+        f32x4 fa[2][RT], fb[2][CT];
+        auto read_frags = [&](int buf, int kk, int set) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                fa[set][rt] = *reinterpret_cast<const f32x4*>(&As[buf][(wrow + rt * 16 + lr) * LDK + kk * 16 + q * 4]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                fb[set][ct] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wcol + ct * 16 + lr) * LDK + kk * 16 + q * 4]);
+        };
+        auto mfma_set = [&](int set) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][rt][j], fb[set][ct][j], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        load_chunk(cbeg, ra0, rb0);
+        store_chunk(0, ra0, rb0);
+        __syncthreads();
+        read_frags(0, 0, 0);
+        for (int c = cbeg; c < nchunks; ++c) {
+            const int buf = (c - cbeg) & 1;
+            const bool more = c + 1 < nchunks;
+            if (more) load_chunk(c + 1, ra0, rb0);
+            read_frags(buf, 1, 1);
+            mfma_set(0);
+            if (more) store_chunk(buf ^ 1, ra0, rb0);
+            __syncthreads();
+            if (more) read_frags(buf ^ 1, 0, 0);
+            mfma_set(1);
+        }
+        __syncthreads();   // the epilogue's statistics reuse the A image
     } else {
         // distance-1 prefetch: one register set keeps the 128-row tiles at two workgroups per CU
         load_chunk(cbeg, ra0, rb0);

@@ -289,7 +289,7 @@ def test_wgrad_workspace_partial_batches_advice_r1(B):
     (corrupting gradients or faulting).  One train step at such a B, then a full-batch step on the same net.
     At this size (8 M activations per layer) a handful of ReLU / max-pool decisions sit within fp32 rounding of a tie,
     so the fp32 oracle itself is 1e-4..1e-3 away from the same net evaluated in float64 (measured: tools/debug/
-    grad_vs_fp64.py); the gate is therefore against the float64 oracle: HIP no further from it than 5e-4 or 5x the
+    grad_vs_fp64.py); the gate is therefore against the float64 oracle: HIP no further from it than 5e-3 or 5x the
     fp32 oracle's own distance.  A corrupted slab is an O(1) error."""
     gene, classes, seed = (32, 3, 1, 1, 1, 0), 10, 9
     cfg = EvalConfig(variant="A", classes=classes, batch=64, eval_batch=64)
@@ -307,7 +307,10 @@ def test_wgrad_workspace_partial_batches_advice_r1(B):
                 worst = max(e_hip, key=e_hip.get)
                 print(f"B={b}: worst HIP-vs-fp64 {worst} {e_hip[worst]:.2e} (fp32 oracle vs fp64 there: {e_o32[worst]:.2e})")
                 for name in e_hip:
-                    assert e_hip[name] <= max(5e-4, 5.0 * e_o32[name]), (name, e_hip[name], e_o32[name])
+                    # 5e-3: a flipped pool / ReLU decision moves a tensor by ~1e-3 of its max (it happens on either side:
+                    # HIP 1.2e-3 with the fp32 oracle at 6e-6, and the reverse, were both observed); a slab written
+                    # past the workspace or summed from stale memory is >= 1e-2 and usually O(1)
+                    assert e_hip[name] <= max(5e-3, 5.0 * e_o32[name]), (name, e_hip[name], e_o32[name])
         lg, _ = net.train_metrics()          # summed loss of both steps: the second step ran on sane weights
         assert np.isfinite(lg)
         l_o, a_o, _ = o32.evaluate(X, y)
