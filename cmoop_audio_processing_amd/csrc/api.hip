@@ -341,7 +341,13 @@ int cmoop_conv_bwd(const float* x, const float* w, const float* dy, float* dx, f
         CMOOP_HIP(hipMalloc(&wg, wg_floats * 4));
         CMOOP_HIP(hipMalloc(&red, ((size_t)1024 * 2 * Cout + 2 * Cout + 64) * 4));
         CMOOP_HIP(hipMalloc(&wd, (size_t)g.Cout * g.K() * 4));
-        conv_backward_weights(x, dy, dw, db, g, wg, wg_floats, s, nullptr);
+        void* tab = nullptr;
+        const int tab_rows = (KS * KS <= 32) ? rowtab_rows(g) : 0;
+        if (tab_rows) {
+            CMOOP_HIP(hipMalloc(&tab, (size_t)tab_rows * 8));
+            launch_build_rowtab(g, tab, s);
+        }
+        conv_backward_weights(x, dy, dw, db, g, wg, wg_floats, s, nullptr, GEMM_DEFAULT, tab, tab_rows);
         if (dx) {
             int accumulate = 0;
             if (stride != 1) {
@@ -357,6 +363,7 @@ int cmoop_conv_bwd(const float* x, const float* w, const float* dy, float* dx, f
         CMOOP_HIP(hipStreamSynchronize(s));
         hipFree(wg); hipFree(red); hipFree(wd);
         if (sk) hipFree(sk);
+        if (tab) hipFree(tab);
     });
 }
 
@@ -378,13 +385,19 @@ int cmoop_conv_time(int32_t mode, const float* x, const float* w, const float* b
             gd.H = g.OH; gd.W = g.OW; gd.Cin = Cout; gd.Cout = Cin; gd.OH = g.H; gd.OW = g.W;
             gd.pad_t = KS - 1 - g.pad_t; gd.pad_l = KS - 1 - g.pad_l;
         }
+        void* tab = nullptr;
+        const int tab_rows = (mode == 2 && KS * KS <= 32) ? rowtab_rows(g) : 0;
         if (mode == 2) CMOOP_HIP(hipMalloc(&wg, (size_t)S * g.Cout * g.K() * 4));
+        if (tab_rows) {
+            CMOOP_HIP(hipMalloc(&tab, (size_t)tab_rows * 8));
+            launch_build_rowtab(g, tab, s);
+        }
         const size_t skf = mode == 0 ? igemm_splitk_workspace(g) : (mode == 1 ? igemm_splitk_workspace(gd) : 0);
         if (skf) CMOOP_HIP(hipMalloc(&sk, skf * 4));
         auto once = [&]() {
             if (mode == 0) launch_igemm_fwd(x, w, y, g, e, s, nullptr, sk, skf);
             else if (mode == 1) launch_igemm_fwd(y, wd, const_cast<float*>(x), gd, e, s, nullptr, sk, skf);
-            else launch_igemm_wgrad(x, y, wg, g, S, s);
+            else launch_igemm_wgrad(x, y, wg, g, S, s, nullptr, nullptr, 0, GEMM_DEFAULT, tab, tab_rows);
         };
         for (int i = 0; i < 3; ++i) once();
         hipEvent_t a, b;
@@ -400,6 +413,7 @@ int cmoop_conv_time(int32_t mode, const float* x, const float* w, const float* b
         if (wd) hipFree(wd);
         if (wg) hipFree(wg);
         if (sk) hipFree(sk);
+        if (tab) hipFree(tab);
         *avg_ms = (double)ms / std::max(1, iters);
     });
 }

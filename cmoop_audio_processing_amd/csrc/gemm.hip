@@ -749,10 +749,45 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
 // ds_read_b128 as in the forward kernel -- conflict-free with pitch 40 + XOR swizzle, coalesced gathers -- ran 8 %
 // slower than this m-major image with ds_read_b32 fragments: 95 vs 103 TFLOP/s on 128->128 k5.)
 // ---------------------------------------------------------------------------
+// Row table of a conv layer (one entry per output pixel row m of the implicit GEMM, padded to a multiple of 32 rows):
+//   .x = byte offset of input pixel (b, oh*stride - pad_t, ow*stride - pad_l), channel 0, biased by
+//        (pad_t*W + pad_l)*Cin*4 so it is never negative (the buffer descriptor's base is moved back by the same bias)
+//   .y = bitmask of the filter taps that fall into the SAME padding for this row (all ones for padding rows >= M)
+// It depends on the layer geometry only, so the trainer builds it once per layer; the weight-gradient kernel then
+// needs no divisions, no bounds arithmetic and no 64-bit pointer math per gathered element (see load_chunk_fast).
+__global__ __launch_bounds__(256) void build_rowtab_kernel(GeomDev g, uint2* __restrict__ tab, int rows_padded) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows_padded) return;
+    if (m >= g.M) { tab[m] = make_uint2(0u, 0xFFFFFFFFu); return; }
+    const int b = fastdiv(m, g.ohw_magic, g.ohw_shift), r = m - b * g.OHW;
+    const int oh = fastdiv(r, g.ow_magic, g.ow_shift), ow = r - oh * g.OW;
+    const int ih0 = oh * g.stride - g.pad_t, iw0 = ow * g.stride - g.pad_l;
+    const int hlo = max(0, -ih0), hhi = min(g.KH, g.H - ih0);
+    const int wlo = max(0, -iw0), whi = min(g.KW, g.W - iw0);
+    const uint32_t wmask = (whi > wlo) ? (((1u << whi) - 1u) & ~((1u << wlo) - 1u)) : 0u;
+    uint32_t okm = 0;
+    for (int kh = 0; kh < g.KH; ++kh)
+        if (kh >= hlo && kh < hhi) okm |= wmask << (kh * g.KW);
+    const uint32_t bias = (uint32_t)((g.pad_t * g.W + g.pad_l) << g.cshift);
+    tab[m] = make_uint2(((uint32_t)(((b * g.H + ih0) * g.W + iw0) << g.cshift) + bias) * 4u, ~okm);
+}
+
+int rowtab_rows(const ConvGeom& g) { return cdiv(g.M(), 32) * 32; }
+
+void launch_build_rowtab(const ConvGeom& cg, void* tab, hipStream_t s) {
+    GeomDev g = to_dev(cg);
+    CMOOP_REQUIRE(g.KH * g.KW <= 32, "row table: at most 32 filter taps");
+    const int rows = rowtab_rows(cg);
+    if (rows == 0) return;
+    hipLaunchKernelGGL(build_rowtab_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, g, static_cast<uint2*>(tab), rows);
+    CMOOP_HIP(hipGetLastError());
+}
+
 template <int BCO, int BKI>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                           float* __restrict__ P, GeomDev g, int rows_per_slice,
-                                                          float* __restrict__ Pbias, size_t slab_stride) {
+                                                          float* __restrict__ Pbias, size_t slab_stride,
+                                                          const uint2* __restrict__ rowtab, int tab_rows) {
     constexpr int MC = 32;
     constexpr int LDX = BKI + 16;                          // == 16 mod 32
     constexpr int LDY = (BCO == 16) ? 16 : BCO + 16;
@@ -781,6 +816,41 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     const bool cok = (co0 + 4 * yq) < g.Cout;   // Cout % 4 may be != 0: guarded per element below
 
     f32x4 rx[XPASS], ry[YPASS];
+    // ---- fast gather (row table present): buffer loads, the row's offset / padding mask from the table (fetched one
+    // chunk ahead), this thread's fixed tap offset added on the VALU (3 VALU per gathered float4 instead of ~25), dY
+    // through a fixed voffset + scalar row offset (0 VALU).  Rows >= M read zeros through the descriptors' range checks.
+    const bool fast = rowtab != nullptr && (g.Cout & 3) == 0;
+    const uint32_t x_bias = (uint32_t)((g.pad_t * g.W + g.pad_l) << g.cshift);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X) - x_bias, 0, (int)(((uint32_t)g.B * g.H * g.W << g.cshift) + x_bias) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY), 0, g.M * g.Cout * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2*>(rowtab), 0, fast ? tab_rows * 8 : 0, 0x00020000);
+    const uint32_t koff = (uint32_t)((((kh * g.W + kw) << g.cshift) + ci) * 4);
+    const uint32_t kdead = kok ? 0u : 0xFFFFFFFFu;
+    uint32_t y_voff[YPASS];
+#pragma unroll
+    for (int p = 0; p < YPASS; ++p) {
+        const int rl = yrow + p * RPPY;
+        y_voff[p] = (rl < MC && cok) ? (uint32_t)(rl * g.Cout + co0 + 4 * yq) * 4u : 0xFFFFFFF0u;
+    }
+    uint2 te[XPASS];     // table entries of the chunk whose X loads are issued next
+    auto load_tab = [&](int mc) {
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(tr, (xrow + p * RPPX) * 8, mc * 8, 0);
+            te[p] = make_uint2(v[0], v[1]);
+        }
+    };
+    auto load_chunk_fast = [&](int mc) {
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const uint32_t dead = (uint32_t)__builtin_amdgcn_sbfe((int)te[p].y, tap, 1);
+            rx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)((te[p].x + koff) | dead | kdead), 0, 0));
+        }
+#pragma unroll
+        for (int p = 0; p < YPASS; ++p)
+            ry[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, (int)y_voff[p], mc * g.Cout * 4, 0));
+    };
     auto load_chunk = [&](int mc) {
 #pragma unroll
         for (int p = 0; p < XPASS; ++p) {
@@ -834,7 +904,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const int nchunks = (mend > mbeg) ? (mend - mbeg + MC - 1) / MC : 0;
     if (nchunks > 0) {
-        load_chunk(mbeg);
+        if (fast) {
+            load_tab(mbeg);
+            load_chunk_fast(mbeg);
+            if (nchunks > 1) load_tab(mbeg + MC);
+        } else {
+            load_chunk(mbeg);
+        }
         store_chunk(0);
     }
     __syncthreads();
@@ -844,7 +920,14 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
 #pragma unroll
             for (int p = 0; p < YPASS; ++p) bsum += ry[p];   // ry still holds chunk c (rows past mend are zero)
         }
-        if (c + 1 < nchunks) load_chunk(mbeg + (c + 1) * MC);
+        if (c + 1 < nchunks) {
+            if (fast) {
+                load_chunk_fast(mbeg + (c + 1) * MC);                       // its table entries arrived during chunk c - 1
+                if (c + 2 < nchunks) load_tab(mbeg + (c + 2) * MC);
+            } else {
+                load_chunk(mbeg + (c + 1) * MC);
+            }
+        }
         // fragments of step st+1 are read while the MFMAs of step st issue (two register sets): with eight
         // 4-row steps per chunk an un-pipelined loop exposes the LDS latency eight times per chunk
         float a[2][CPW], b[2][KPW];
@@ -1081,7 +1164,7 @@ int wgrad_slices(const ConvGeom& g) {
 }
 
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s,
-                       const GemmTiming* tm, float* Pbias, size_t slab_stride, int mode_req) {
+                       const GemmTiming* tm, float* Pbias, size_t slab_stride, int mode_req, const void* rowtab, int tab_rows) {
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
     const size_t stride = slab_stride ? slab_stride : (size_t)g.Cout * g.K;
@@ -1097,6 +1180,8 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     // fp32-accurate choice there.  (GEMM_BF16 must round everywhere to stay consistent with its definition.)
     if (mode == GEMM_BF16X3 && bco < 128) mode = GEMM_FP32;
     dim3 grid(cdiv(g.K, bki), cdiv(N, bco), S);
+    // the row table must cover every row a chunk can touch (rows are consumed 32 at a time)
+    const uint2* rt = (rowtab && tab_rows >= cdiv(g.M, 32) * 32 && g.KH * g.KW <= 32) ? static_cast<const uint2*>(rowtab) : nullptr;
 #define CMOOP_WGK(KERNEL)                                                                                       \
     do {                                                                                                       \
         if (tm && tm->start && tm->ext) {                                                                      \
@@ -1107,11 +1192,21 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
             if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));                                       \
         }                                                                                                      \
     } while (0)
+#define CMOOP_WGF(KERNEL)                                                                                       \
+    do {                                                                                                       \
+        if (tm && tm->start && tm->ext) {                                                                      \
+            hipExtLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps, Pbias, stride, rt, tab_rows); \
+        } else {                                                                                               \
+            if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));                                      \
+            hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, X, dY, P, g, rps, Pbias, stride, rt, tab_rows);   \
+            if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));                                       \
+        }                                                                                                      \
+    } while (0)
 #define CMOOP_WG2(BCO_, BKI_)                                                          \
     do {                                                                               \
         if (mode == GEMM_BF16X3) CMOOP_WGK((igemm_wgrad_bf16_kernel<BCO_, BKI_, 3>));  \
         else if (mode == GEMM_BF16) CMOOP_WGK((igemm_wgrad_bf16_kernel<BCO_, BKI_, 1>)); \
-        else CMOOP_WGK((igemm_wgrad_kernel<BCO_, BKI_>));                              \
+        else CMOOP_WGF((igemm_wgrad_kernel<BCO_, BKI_>));                              \
     } while (0)
 #define CMOOP_WG(BCO_)                    \
     do {                                  \
@@ -1124,6 +1219,7 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     else CMOOP_WG(128);
 #undef CMOOP_WG
 #undef CMOOP_WG2
+#undef CMOOP_WGF
 #undef CMOOP_WGK
     CMOOP_HIP(hipGetLastError());
     return mode * 1000000 + bco * 1000 + bki;

@@ -64,9 +64,14 @@ int wgrad_slices(const ConvGeom& g);
 // Pbias (optional): [S][N] per-slice column sums of dY (the bias gradient), fused into the first K tile's blocks
 // slab_stride: floats between consecutive slices of P and of Pbias (0 = N*K, bias slabs packed [S][N]);
 // the trainer lays slices out as [S][N*K + N] so one reduction yields kernel and bias gradients.
+// rowtab (optional, fp32 kernel): the layer's row table (launch_build_rowtab, tab_rows = rowtab_rows(geometry it was
+// built for) >= this launch's rows rounded up to 32) -- switches the gather to buffer loads without per-element
+// divisions / bounds arithmetic.  A table built for the full batch serves every smaller batch of the same layer.
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& g, int S, hipStream_t s,
                        const GemmTiming* tm = nullptr, float* Pbias = nullptr, size_t slab_stride = 0,
-                       int mode = GEMM_DEFAULT);
+                       int mode = GEMM_DEFAULT, const void* rowtab = nullptr, int tab_rows = 0);
+int rowtab_rows(const ConvGeom& g);                                           // entries (8 bytes each) the table needs
+void launch_build_rowtab(const ConvGeom& g, void* tab, hipStream_t s);        // needs KH*KW <= 32
 // out[i] = sum_s P[s][i]  (fixed order -> deterministic)
 void launch_reduce_slices(const float* P, float* out, int S, int64_t n, hipStream_t s, int64_t stride = 0);
 // Wd[ci][KH-1-kh][KW-1-kw][co] = W[co][kh][kw][ci]   (operand of the dgrad implicit GEMM)

@@ -48,7 +48,8 @@ struct GemmHook {   // brackets every MFMA GEMM launch (HIP-event sampling)
 };
 // wgrad_ws holds wgrad_ws_floats floats; the slice count is clamped to what fits (never written past)
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
-                           size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode = GEMM_DEFAULT);
+                           size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode = GEMM_DEFAULT,
+                           const void* rowtab = nullptr, int tab_rows = 0);
 // wd_ready: wd_ws already holds the flip-transposed weights (the trainer refreshes all layers in one launch per step)
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
                         float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws = nullptr,
@@ -79,6 +80,8 @@ struct Op {
     int relu = 0, need_dgrad = 1, in_is_relu = 0, dgrad_accumulate = 0, dropout_layer = -1;
     float in_mask_scale = 1.f;
     int gemm_mode = GEMM_FP32;   // arithmetic of this layer's three GEMMs
+    void* rowtab = nullptr;    // conv: row table of the layer at the train batch (weight-gradient gather)
+    int rowtab_rows = 0;
     int64_t w_off = 0, b_off = 0, wd_off = -1;   // wd_off: this layer's slice of the flip-transposed copy (dgrad operand)
     int tensor_index = 0;   // canonical index of the kernel tensor (RNG init stream)
     // bn

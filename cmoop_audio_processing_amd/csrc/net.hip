@@ -349,6 +349,11 @@ void Net::build_plan() {
         }
         if (op.kind == OP_CONV) {   // (dense layers need no workspace: dense.hip)
             const ConvGeom g = geom_of(op, cfg_.batch);
+            if (op.KS * op.KS <= 32) {   // row table of the layer (geometry only): built once, serves every train batch size
+                op.rowtab_rows = rowtab_rows(g);
+                op.rowtab = dalloc((size_t)op.rowtab_rows * 2);
+                launch_build_rowtab(g, op.rowtab, stream_);
+            }
             // the slice count is NOT monotone in the batch rows (a smaller M can flip the K-tile width and the
             // co-resident workgroup count, so a partial last batch may ask for MORE slices than the full one):
             // size the slab workspace for the worst train batch 1..cfg.batch
@@ -465,7 +470,7 @@ void Net::end(int code) {
 
 // dW[N][K] and db[N] of a conv / dense layer: MFMA split over row slices, then a fixed-order slice sum
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
-                           size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode) {
+                           size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode, const void* rowtab, int tab_rows) {
     const int M = g.M(), N = g.Cout, K = g.K();
     int S = wgrad_slices(g);
     // never write past the slab workspace: fewer slices is always correct (each slice is a row range)
@@ -479,7 +484,7 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
     float* Pk = in_place ? dW : wgrad_ws;
     float* Pbias = in_place ? dB : wgrad_ws + NK;
     const GemmTiming* tm = hook ? hook->begin(1, 2.0 * M * (double)N * K) : nullptr;
-    const int code = launch_igemm_wgrad(X, dY, Pk, g, S, s, tm, Pbias, in_place ? NK : stride, mode);
+    const int code = launch_igemm_wgrad(X, dY, Pk, g, S, s, tm, Pbias, in_place ? NK : stride, mode, rowtab, tab_rows);
     if (hook) hook->end(code);
     if (!in_place) {
         if (dB == dW + NK) {
@@ -657,7 +662,8 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B) {
             // (measured, not adopted: wgrad on a low-priority side stream forked per layer and joined before Adam -- off the
             // dgrad critical path -- ran 35 % SLOWER, 65 vs 100 TFLOP/s whole-job: the cross-stream event waits cost more
             // than the overlap wins)
-            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, wgrad_ws_floats_, stream_, this, op.gemm_mode);
+            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, wgrad_ws_floats_, stream_, this, op.gemm_mode,
+                                  op.rowtab, op.rowtab_rows);
             if (op.need_dgrad)
                 conv_backward_data(dY, params_ + op.w_off, ia.grad, g, wd_ws_ + op.wd_off, op.in_is_relu ? ia.data : nullptr,
                                    op.in_mask_scale, op.dgrad_accumulate, stream_, this, splitk_ws_, splitk_ws_floats_, op.gemm_mode,
