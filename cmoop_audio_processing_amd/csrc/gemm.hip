@@ -77,6 +77,7 @@ struct GeomDev {
     const float* zeros;    // 16 zero floats: predicated-off lanes load from here (branch-free gathers)
 };
 struct EpiDev {
+    int bal_L, bal_segmax; // balanced K partition (bal_L > 0): K-chunk units per workgroup, partial-tile slots per tile in the slab
     float* stats;          // non-null: per-M-tile column partials (sum v, sum v^2) of the stored values, [tiles][2][N] (BatchNorm batch statistics)
     const float* bias;
     const float* mask;
@@ -177,17 +178,50 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) unsigned short Bh[NP][PLANES ? BN * LDH : 8];
 
     const int t = threadIdx.x;
-    // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each
-    // XCD a contiguous run of M tiles -- neighbouring tiles share their im2col halo in that XCD's L2.
-    int mtile = blockIdx.x;
-    {
+    const int lrow = t / TPR, kq = t % TPR;
+    const int chunks_total = (g.K + BK - 1) / BK;
+    // Balanced K partition (e.bal_L > 0; under-filled grids: the 26x10 / 13x5 layers): the launch's work is the
+    // linear sequence of (tile, K chunk) units, tile-major, and workgroup w owns units [w L, (w+1) L) -- every
+    // workgroup the SAME number of chunks, whatever the tile count is against the chip's 512 workgroup slots
+    // (uniform split-K left 11-49 % of a wave of slots empty: 260 tiles x 7 splits on 512 slots).  A range crosses at
+    // most one tile boundary (L <= chunks per tile), so a workgroup runs up to two pieces; each piece writes its raw
+    // partial tile into slot (tile, seg) of the slab, seg counting the pieces of that tile in K order, and the
+    // combine kernel adds a tile's pieces in that fixed order (deterministic) before the epilogue.
+    const int pieces = e.bal_L > 0 ? 2 : 1;
+    for (int piece = 0; piece < pieces; ++piece) {
+    int mtile, ntile, cbeg, nchunks;
+    float* pslab = nullptr;
+    if (e.bal_L > 0) {
+        const int nt = (g.Cout + BN - 1) / BN;
+        const int L = e.bal_L;
+        const int U = ((g.M + BM - 1) / BM) * nt * chunks_total;
+        const int u0 = blockIdx.x * L, u1 = min(U, u0 + L);
+        if (u0 >= u1) break;
+        int t0 = u0 / chunks_total;
+        int cb = u0 - t0 * chunks_total, ce = min(chunks_total, cb + (u1 - u0));
+        if (piece == 1) {
+            if (u0 + (ce - cb) >= u1) break;          // the range ended inside its first tile
+            t0 += 1; cb = 0; ce = u1 - t0 * chunks_total;
+            __syncthreads();                          // the first piece's LDS images are dead only now
+        }
+        mtile = t0 / nt; ntile = t0 - mtile * nt;
+        cbeg = cb; nchunks = ce;
+        const int seg = cb == 0 ? 0 : (int)blockIdx.x - (t0 * chunks_total) / L;
+        pslab = slab + ((size_t)t0 * e.bal_segmax + seg) * (BM * BN);
+    } else {
+        // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each
+        // XCD a contiguous run of M tiles -- neighbouring tiles share their im2col halo in that XCD's L2.
+        mtile = blockIdx.x;
         const int nwg = gridDim.x, xcd = mtile & 7, idx = mtile >> 3;
         const int qn = nwg >> 3, rn = nwg & 7;
         mtile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+        ntile = blockIdx.y;
+        // split-K: blockIdx.z owns K chunks [cbeg, nchunks) and writes raw partial sums to its slab
+        cbeg = blockIdx.z * chunks_per_split;
+        nchunks = min(chunks_total, cbeg + chunks_per_split);
     }
     const int m0 = mtile * BM;
-    const int n0 = blockIdx.y * BN;
-    const int lrow = t / TPR, kq = t % TPR;
+    const int n0 = ntile * BN;
 
     // per-pass row decode (fixed over the K loop)
     int a_ih0[APASS], a_iw0[APASS], a_base[APASS];
@@ -378,9 +412,6 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         }
     };
 
-    // split-K: blockIdx.z owns K chunks [cbeg, nchunks) and writes raw partial sums to its slab
-    const int cbeg = blockIdx.z * chunks_per_split;
-    const int nchunks = min((g.K + BK - 1) / BK, cbeg + chunks_per_split);
     if constexpr (PLANES) {
         // single LDS image (bf16 planes per operand), next chunk's global loads in flight during the MFMAs
         // (a two-chunk-deep prefetch in two register sets was measured: it drops the kernel to one workgroup per
@@ -472,6 +503,16 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
 
     // epilogue: C/D map of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg
     const int N = g.Cout;
+    if (pslab) {   // balanced partition: this piece's raw partial tile, [BM][BN] in its (tile, seg) slot
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    pslab[(wrow + rt * 16 + q * 4 + r) * BN + wcol + ct * 16 + lr] = acc[rt][ct][r];
+        continue;
+    }
     if (slab) {   // split-K partial: raw sums, the combine kernel applies the epilogue
         float* Pz = slab + (size_t)blockIdx.z * g.M * N;
 #pragma unroll
@@ -486,7 +527,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
                     if (col < N) Pz[(size_t)row * N + col] = acc[rt][ct][r];
                 }
             }
-        return;
+        continue;
     }
     float csum[CT], csq[CT];
 #pragma unroll
@@ -550,12 +591,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             e.stats[((size_t)mtile * 2 + 1) * N + n0 + t] = b;
         }
     }
+    }   // piece loop
 }
 
 // combine the split-K slabs in fixed order and apply the epilogue (VEC = 4 when N % 4 == 0)
+struct BalDev { int bm, bn, nt, chunks, L, segmax; };   // balanced K partition: tile shape, N tiles, chunks per tile, units per workgroup
+
 template <int VEC>
 __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ P, float* __restrict__ Y, GeomDev g,
-                                                             EpiDev e, int splits) {
+                                                             EpiDev e, int splits, BalDev bal) {
     const int N = g.Cout;
     const size_t total = (size_t)g.M * N;
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += (size_t)gridDim.x * 256 * VEC) {
@@ -563,6 +607,21 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
         float v[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] = 0.f;
+        if (bal.L > 0) {   // pieces of this element's tile, in K order (fixed order -> deterministic)
+            const int mt = row / bal.bm, ntl = col / bal.bn;
+            const int tile = mt * bal.nt + ntl;
+            const int first = (tile * bal.chunks) / bal.L;
+            const int nseg = ((tile + 1) * bal.chunks + bal.L - 1) / bal.L - first;
+            const float* src = P + (size_t)tile * bal.segmax * (bal.bm * bal.bn) + (size_t)(row - mt * bal.bm) * bal.bn + (col - ntl * bal.bn);
+            for (int z = 0; z < nseg; ++z) {
+                if constexpr (VEC == 4) {
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(src + (size_t)z * (bal.bm * bal.bn));
+                    v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+                } else {
+                    v[0] += src[(size_t)z * (bal.bm * bal.bn)];
+                }
+            }
+        } else
         for (int z = 0; z < splits; ++z) {
             if constexpr (VEC == 4) {
                 const f32x4 p = *reinterpret_cast<const f32x4*>(P + (size_t)z * total + i);
@@ -596,12 +655,23 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
 }
 
 template <int BM, int BN, int BK, int WM, int MODE = 0>
-static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDev& g, const EpiDev& e, hipStream_t s,
-                         const GemmTiming* tm, float* slab, int splits) {
+static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDev& g, const EpiDev& e_in, hipStream_t s,
+                         const GemmTiming* tm, float* slab, int splits, int balanced_wgs = 0) {
+    EpiDev e = e_in;
     dim3 grid(cdiv(g.M, BM), cdiv(g.Cout, BN), splits);
     const int nchunks = cdiv(g.K, BK);
-    const int cps = cdiv(nchunks, splits);
+    int cps = cdiv(nchunks, splits);
     float* sl = splits > 1 ? slab : nullptr;
+    BalDev bal{BM, BN, cdiv(g.Cout, BN), nchunks, 0, 0};
+    if (balanced_wgs > 0) {   // balanced K partition: every workgroup gets L chunk units (see the kernel)
+        const long units = (long)grid.x * grid.y * nchunks;
+        bal.L = (int)((units + balanced_wgs - 1) / balanced_wgs);
+        bal.segmax = cdiv(nchunks, bal.L) + 1;
+        e.bal_L = bal.L; e.bal_segmax = bal.segmax;
+        grid = dim3((unsigned)((units + bal.L - 1) / bal.L), 1, 1);
+        sl = slab;
+        splits = 2;            // any value > 1: take the combine path below
+    }
     if (tm && tm->start && tm->ext) {
         hipExtLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM, MODE>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, Wt, Y, g,
                               e, sl, cps);
@@ -615,10 +685,10 @@ static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDe
         const size_t total = (size_t)g.M * g.Cout;
         if (g.Cout % 4 == 0) {
             const unsigned gridc = (unsigned)std::min<size_t>((total / 4 + 255) / 256, 4096);
-            hipLaunchKernelGGL(splitk_combine_kernel<4>, dim3(gridc), dim3(256), 0, s, slab, Y, g, e, splits);
+            hipLaunchKernelGGL(splitk_combine_kernel<4>, dim3(gridc), dim3(256), 0, s, slab, Y, g, e, splits, bal);
         } else {
             const unsigned gridc = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
-            hipLaunchKernelGGL(splitk_combine_kernel<1>, dim3(gridc), dim3(256), 0, s, slab, Y, g, e, splits);
+            hipLaunchKernelGGL(splitk_combine_kernel<1>, dim3(gridc), dim3(256), 0, s, slab, Y, g, e, splits, bal);
         }
         CMOOP_HIP(hipGetLastError());
     }
@@ -653,14 +723,34 @@ static int fill_waves(long base, int max_mult, int resident, double first_thr = 
 // Tile / split choice.  Prefer the big (most efficient) tile; if its grid does not cover the chip
 // (deep layers: 13x5 or 26x10 pixels x 64 samples) split the long K axis across blockIdx.z when a
 // slab workspace is available, else fall back to 64-row tiles.
-static void pick_tile(int M, int N, int K, int bk, size_t ws_floats, int* bm, int* bn, int* splits) {
+// workgroups co-resident on the chip for the 128-row, 32-deep instantiations (LDS-limited: 2 per CU at 64/128 columns, 3 below)
+static inline int resident_wgs_128(int bn) { return 256 * (bn >= 64 ? 2 : 3); }
+
+// balanced K partition of an under-filled launch (see igemm_fwd_kernel): slab floats it needs, 0 if not applicable
+static size_t balanced_slab_floats(int M, int N, int K, int bk, int bn, int* wgs_out) {
+    if (bk != 32) return 0;
+    const long tiles = (long)cdiv(M, 128) * cdiv(N, bn);
+    const int chunks = cdiv(K, 32), W = resident_wgs_128(bn);
+    if (tiles > W || tiles * chunks < 8l * W) return 0;          // at most two pieces per workgroup; at least 8 chunks each
+    const int L = (int)((tiles * chunks + W - 1) / W);
+    if (wgs_out) *wgs_out = W;
+    return (size_t)tiles * (cdiv(chunks, L) + 1) * 128 * bn;
+}
+
+static void pick_tile(int M, int N, int K, int bk, size_t ws_floats, int* bm, int* bn, int* splits, int* balanced_wgs) {
     const int bn_small = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
     const int bn_big = N > 64 ? 128 : bn_small;
     *splits = 1;
+    *balanced_wgs = 0;
     long blocks = (long)cdiv(M, 128) * cdiv(N, bn_big);
     const long fill = std::max(32l, (long)(384 * par_scale()));
     if (blocks >= fill) { *bm = 128; *bn = bn_big; return; }
     const int nchunks = cdiv(K, bk);
+    {
+        int W = 0;
+        const size_t need = balanced_slab_floats(M, N, K, bk, bn_big, &W);
+        if (need > 0 && need <= ws_floats) { *bm = 128; *bn = bn_big; *balanced_wgs = W; return; }
+    }
     if (nchunks >= (M <= 512 ? 4 : 16) && ws_floats > 0) {
         // dense layers (M = batch rows) are a serial latency chain of K chunks: split them finely
         const int min_chunks = M <= 512 ? 2 : 8;
@@ -687,7 +777,7 @@ size_t igemm_splitk_workspace(const ConvGeom& g) {
     const long blocks = (long)cdiv(M, 128) * cdiv(N, bn_big);
     if (blocks >= 384) return 0;
     const int sp = std::min(32, cdiv(1024, (int)blocks));
-    return (size_t)sp * M * N;
+    return std::max((size_t)sp * M * N, balanced_slab_floats(M, N, g.K(), g.Cin % 32 == 0 ? 32 : 16, bn_big, nullptr));
 }
 
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& cg, const GemmEpilogue& ep,
@@ -705,21 +795,22 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     // bf16 planes always use 32-deep chunks (a chunk may span two taps of a 16-channel layer; the per-thread tap decode
     // and the k < K guard handle that)
     const bool bk32 = mode != GEMM_FP32 || (g.Cin % 32 == 0);
-    int bm, bn, splits;
-    pick_tile(g.M, g.Cout, g.K, bk32 ? 32 : 16, splitk_ws ? splitk_ws_floats : 0, &bm, &bn, &splits);
+    int bm, bn, splits, balanced_wgs;
+    pick_tile(g.M, g.Cout, g.K, bk32 ? 32 : 16, splitk_ws ? splitk_ws_floats : 0, &bm, &bn, &splits, &balanced_wgs);
+    e.bal_L = 0; e.bal_segmax = 0;
     // fused column statistics only on un-split launches (split-K partials are raw sums; the caller falls back to the
     // stand-alone reduction there: those are the small 13x5 / 26x10 layers)
-    e.stats = (ep.stats && stats_blocks && splits == 1 && ep.out_stride == 1 && !ep.accumulate) ? ep.stats : nullptr;
+    e.stats = (ep.stats && stats_blocks && splits == 1 && !balanced_wgs && ep.out_stride == 1 && !ep.accumulate) ? ep.stats : nullptr;
     if (e.stats) *stats_blocks = cdiv(g.M, bm);
     // many-wave grids of 128x64 tiles run 3-4 % faster with 16-deep K chunks (half the LDS, 4-5 workgroups
     // per CU instead of 2); single-wave grids prefer the 32-deep chunk (half the barriers)
     const bool bk32_tile = mode != GEMM_FP32 ||
-                           (bk32 && !(bm == 128 && bn == 64 && splits == 1 && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024));
+                           (bk32 && !(bm == 128 && bn == 64 && splits == 1 && !balanced_wgs && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024));
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \
     do {                                                                                      \
-        if (mode == GEMM_BF16X3) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16X3>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);   \
-        else if (mode == GEMM_BF16) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);  \
-        else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);   \
+        if (mode == GEMM_BF16X3) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16X3>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);   \
+        else if (mode == GEMM_BF16) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);  \
+        else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);   \
         else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);        \
     } while (0)
     if (bm == 128) {
