@@ -746,7 +746,12 @@ static void pick_tile(int M, int N, int K, int bk, size_t ws_floats, int* bm, in
     const long fill = std::max(32l, (long)(384 * par_scale()));
     if (blocks >= fill) { *bm = 128; *bn = bn_big; return; }
     const int nchunks = cdiv(K, bk);
-    {
+    // Balanced K partition: +11..26 % on the 26x10 / 13x5 layer shapes with the launch ALONE on the chip, but 1.3 % SLOWER
+    // whole-job (2 094 vs 2 121 evals/h): with eight candidates in flight the empty slots of a ragged wave are filled by
+    // the other streams' workgroups anyway, and 512 long workgroups balance worse against that traffic than 1 820 short
+    // ones.  Kept for single-stream use (CMOOP_BALANCED=1, e.g. one candidate per GPU); off by default.
+    static const bool balanced_on = [] { const char* v = std::getenv("CMOOP_BALANCED"); return v && v[0] == '1'; }();
+    if (balanced_on) {
         int W = 0;
         const size_t need = balanced_slab_floats(M, N, K, bk, bn_big, &W);
         if (need > 0 && need <= ws_floats) { *bm = 128; *bn = bn_big; *balanced_wgs = W; return; }
@@ -813,6 +818,7 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
         else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);   \
         else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);        \
     } while (0)
+    // (Measured, not adopted: 256x64 tiles for the 64-column layers at 101x40 -- 109.6 vs 118.5 TFLOP/s forward.)
     if (bm == 128) {
         if (bn == 128) CMOOP_FWD(128, 128, 2);
         else if (bn == 64) CMOOP_FWD(128, 64, 4);
