@@ -48,6 +48,8 @@ struct DenseEpi {
     int relu, dropout;
     uint32_t drop_prefix, drop_thr;
     float drop_scale;
+    const StepState* st;              // non-null: drop_prefix = rng_prefix(drop_seed, drop_stream, st->step)
+    uint32_t drop_seed, drop_stream;
 };
 
 // Y[m][n] = act(sum_k X[m][k] * W[n][k] + bias[n])
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict_
     const int col = n0 + lr;
     if (col >= N) return;
     const float bv = e.bias ? e.bias[col] : 0.f;
+    const uint32_t prefix = (e.dropout && e.st) ? rng_prefix(e.drop_seed, e.drop_stream, e.st->step) : e.drop_prefix;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = m0 + 4 * q + r;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict_
         float v = acc[r] + bv;
         if (e.relu) v = fmaxf(v, 0.f);
         if (e.dropout) {
-            const uint32_t u24 = fmix32(e.drop_prefix ^ (uint32_t)((size_t)row * N + col)) >> 8;
+            const uint32_t u24 = fmix32(prefix ^ (uint32_t)((size_t)row * N + col)) >> 8;
             v = (u24 >= e.drop_thr) ? v * e.drop_scale : 0.f;
         }
         Y[(size_t)row * N + col] = v;
@@ -204,10 +207,11 @@ static void check_dense(int M, int N, int K) {
 }
 
 void launch_dense_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int relu,
-                      int dropout, uint32_t drop_prefix, uint32_t drop_thr, float drop_scale, int mode, hipStream_t s) {
+                      int dropout, uint32_t drop_prefix, uint32_t drop_thr, float drop_scale, int mode, hipStream_t s,
+                      const StepState* st, uint32_t drop_seed, uint32_t drop_stream) {
     check_dense(M, N, K);
     if (M == 0) return;
-    DenseEpi e{bias, relu, dropout, drop_prefix, drop_thr, drop_scale};
+    DenseEpi e{bias, relu, dropout, drop_prefix, drop_thr, drop_scale, st, drop_seed, drop_stream};
     const unsigned grid = (unsigned)(cdiv(M, 16) * cdiv(N, 16));
     hipLaunchKernelGGL(dense_fwd_kernel, dim3(grid), dim3(256), 0, s, X, W, Y, M, N, K, e, mode == GEMM_BF16 ? 1 : 0, dense_zero_page());
     CMOOP_HIP(hipGetLastError());

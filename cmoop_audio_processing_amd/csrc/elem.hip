@@ -19,9 +19,10 @@ template <int KS>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx,
                                                         int64_t row0, const float* __restrict__ Wt,
                                                         const float* __restrict__ bias, float* __restrict__ Y, int B,
-                                                        int H, int W, int Cout, int relu) {
+                                                        int H, int W, int Cout, int relu, const StepState* __restrict__ st) {
     constexpr int TAPS = KS * KS, SEG = 4 + KS - 1, p = (KS - 1) >> 1;
     __shared__ __attribute__((aligned(16))) float Ws[TAPS * 64];
+    if (st) row0 = st->row0;
     const int t = threadIdx.x;
     for (int i = t; i < TAPS * Cout; i += 256) {
         int co = i / TAPS, tap = i - co * TAPS;
@@ -71,14 +72,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 }
 
 void launch_conv1_fwd(const float* X, const int32_t* idx, int64_t row0, const float* Wt, const float* bias, float* Y,
-                      int B, int H, int W, int Cout, int KS, int relu, hipStream_t s) {
+                      int B, int H, int W, int Cout, int KS, int relu, hipStream_t s, const StepState* st) {
     CMOOP_REQUIRE(Cout % 4 == 0 && Cout <= 64 && 64 % (Cout / 4) == 0 && (KS == 3 || KS == 5), "conv1: unsupported shape");
     const int GPB = 256 / (Cout / 4);
     const int64_t groups = (int64_t)B * H * ((W + 3) / 4);
     if (groups == 0) return;
     const dim3 grid((unsigned)cdiv64(groups, GPB));
-    if (KS == 3) hipLaunchKernelGGL(conv1_fwd_kernel<3>, grid, dim3(256), 0, s, X, idx, row0, Wt, bias, Y, B, H, W, Cout, relu);
-    else hipLaunchKernelGGL(conv1_fwd_kernel<5>, grid, dim3(256), 0, s, X, idx, row0, Wt, bias, Y, B, H, W, Cout, relu);
+    if (KS == 3) hipLaunchKernelGGL(conv1_fwd_kernel<3>, grid, dim3(256), 0, s, X, idx, row0, Wt, bias, Y, B, H, W, Cout, relu, st);
+    else hipLaunchKernelGGL(conv1_fwd_kernel<5>, grid, dim3(256), 0, s, X, idx, row0, Wt, bias, Y, B, H, W, Cout, relu, st);
     CMOOP_HIP(hipGetLastError());
 }
 
@@ -90,9 +91,11 @@ int conv1_wgrad_blocks(int B, int H, int W) {
 template <int KS>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx,
                                                           int64_t row0, const float* __restrict__ dY,
-                                                          float* __restrict__ P, int B, int H, int W, int Cout) {
+                                                          float* __restrict__ P, int B, int H, int W, int Cout,
+                                                          const StepState* __restrict__ st) {
     constexpr int TAPS = KS * KS, SEG = 4 + KS - 1, p = (KS - 1) >> 1;
     __shared__ float red[4 * (TAPS + 1) * 64];
+    if (st) row0 = st->row0;
     const int t = threadIdx.x;
     const int TPG = Cout >> 2, GPB = 256 / TPG;
     const int gl = t / TPG, c4 = t % TPG;
@@ -165,11 +168,11 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
 }
 
 void launch_conv1_wgrad(const float* X, const int32_t* idx, int64_t row0, const float* dY, float* P, int B, int H,
-                        int W, int Cout, int KS, hipStream_t s) {
+                        int W, int Cout, int KS, hipStream_t s, const StepState* st) {
     CMOOP_REQUIRE(Cout % 4 == 0 && Cout <= 64 && 64 % (Cout / 4) == 0, "conv1 wgrad: unsupported Cout");
     const int nb = conv1_wgrad_blocks(B, H, W);
-    if (KS == 3) hipLaunchKernelGGL(conv1_wgrad_kernel<3>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout);
-    else if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_kernel<5>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout);
+    if (KS == 3) hipLaunchKernelGGL(conv1_wgrad_kernel<3>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout, st);
+    else if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_kernel<5>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout, st);
     else CMOOP_REQUIRE(false, "conv1 wgrad: kernel size must be 3 or 5");
     CMOOP_HIP(hipGetLastError());
 }
@@ -689,20 +692,41 @@ void launch_add_relu(const float* A, const float* Bt, float* Y, int64_t n, hipSt
     CMOOP_HIP(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ X, float* __restrict__ Y, int B, int HW,
-                                                      int C, float inv) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i - b * C;
-    const float* x = X + (size_t)b * HW * C + c;
-    float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += x[(size_t)p * C];
-    Y[i] = s * inv;
+// GlobalAveragePooling2D: one workgroup per sample; lanes = channel quads, the remaining threads split the pixels;
+// float4 loads, fixed-order LDS reduction over the pixel slices (the old one-thread-per-(b,c) loop took 69 us on a
+// 26x10x32 tensor -- 12 % of a small candidate's step)
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ X, float* __restrict__ Y, int HW, int C,
+                                                      float inv) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    const int t = threadIdx.x, lanes = C >> 2;
+    const int slices = 256 / lanes;
+    const int sl = t / lanes, cl = t - sl * lanes;
+    const float* x = X + (size_t)blockIdx.x * HW * C + 4 * cl;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (sl < slices)
+        for (int p = sl; p < HW; p += slices) s += *reinterpret_cast<const f32x4*>(x + (size_t)p * C);
+    *reinterpret_cast<f32x4*>(&red[t * 4]) = s;
+    __syncthreads();
+    if (sl == 0) {
+        for (int r = 1; r < slices; ++r) s += *reinterpret_cast<const f32x4*>(&red[(r * lanes + cl) * 4]);
+        *reinterpret_cast<f32x4*>(Y + (size_t)blockIdx.x * C + 4 * cl) = s * inv;
+    }
 }
 
 void launch_gap_fwd(const float* X, float* Y, int B, int HW, int C, hipStream_t s) {
     if (B == 0) return;
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, s, X, Y, B, HW, C, (float)(1.0 / HW));
+    CMOOP_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "gap: C must be 4 x a divisor of 256");
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(B), dim3(256), 0, s, X, Y, HW, C, (float)(1.0 / HW));
+    CMOOP_HIP(hipGetLastError());
+}
+
+__global__ void step_advance_kernel(StepState* st, int batch) {
+    st->row0 += batch;
+    st->step += 1;
+    st->iter += 1;
+}
+void launch_step_advance(StepState* st, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, st, batch);
     CMOOP_HIP(hipGetLastError());
 }
 
@@ -737,8 +761,9 @@ void launch_gap_bwd(const float* dY, const float* X, float* dX, int B, int HW, i
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ Z, const int32_t* __restrict__ labels,
                                                          const int32_t* __restrict__ idx, int64_t row0, int B, int C,
                                                          float* __restrict__ dZ, double* __restrict__ acc,
-                                                         int32_t* __restrict__ preds) {
+                                                         int32_t* __restrict__ preds, const StepState* __restrict__ st) {
     __shared__ double lsum[4];
+    if (st) row0 = st->row0;
     __shared__ int csum[4];
     const int t = threadIdx.x;
     const float lo = 1e-7f, hi = 1.0f - 1e-7f;
@@ -797,16 +822,18 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 }
 
 void launch_softmax_ce(const float* Z, const int32_t* labels, const int32_t* idx, int64_t row0, int B, int C, float* dZ,
-                       double* acc, int32_t* preds, hipStream_t s) {
+                       double* acc, int32_t* preds, hipStream_t s, const StepState* st) {
     if (B == 0) return;
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, s, Z, labels, idx, row0, B, C, dZ, acc, preds);
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, s, Z, labels, idx, row0, B, C, dZ, acc, preds, st);
     CMOOP_HIP(hipGetLastError());
 }
 
 // Keras-form Adam: m += (g-m)(1-b1); v += (g^2-v)(1-b2); w -= m*alpha/(sqrt(v)+eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float alpha, float c1, float c2,
-                                                   float eps) {
+                                                   float eps, const StepState* __restrict__ st,
+                                                   const float* __restrict__ alpha_table) {
+    if (st) alpha = alpha_table[st->iter];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i];
         float mi = m[i], vi = v[i];
@@ -819,9 +846,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
 }
 
 void launch_adam(float* w, const float* g, float* m, float* v, int64_t n, float alpha, float c1, float c2, float eps,
-                 hipStream_t s) {
+                 hipStream_t s, const StepState* st, const float* alpha_table) {
     if (n == 0) return;
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, s, w, g, m, v, n, alpha, c1, c2, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, s, w, g, m, v, n, alpha, c1, c2, eps, st, alpha_table);
     CMOOP_HIP(hipGetLastError());
 }
 

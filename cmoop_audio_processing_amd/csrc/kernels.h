@@ -82,13 +82,28 @@ void launch_flip_transpose_all(const float* params, float* wd_all, const FlipEnt
                                hipStream_t s);
 
 // ---------------------------------------------------------------------------
+// Device-resident step state of a candidate's training run.  Every per-step quantity a kernel needs (the batch's first
+// row in the epoch permutation, the step counter that keys the dropout masks, the optimiser iteration that selects
+// Adam's bias-corrected step size) is read from here, so a train step's launch sequence has NO host-side arguments
+// that change from step to step and can be captured once as a hipGraph and replayed (net.hip).
+// ---------------------------------------------------------------------------
+struct StepState {
+    long long row0;        // first row of the current batch in idx (advanced by the batch size after every step)
+    unsigned step;         // global train step (dropout counter)
+    unsigned iter;         // optimizer.iterations BEFORE this step's update (alpha_table[iter] is its step size)
+};
+void launch_step_advance(StepState* st, int batch, hipStream_t s);
+
+// ---------------------------------------------------------------------------
 // Dense layers of the MLP head (dense.hip): M = batch rows, K = C_in (multiple of 16), N = units (any).
 // One workgroup per 16x16 output tile, operands read straight from global memory in the MFMA lane layout,
 // fixed-order 4-wave reduction: no split-K slabs, no flip-transposed weights, no slice reduction.
 // mode GEMM_BF16 rounds both operands to bf16 (fp32 accumulation); every other mode is exact fp32.
 // ---------------------------------------------------------------------------
+// dropout: st == null -> mask keyed by drop_prefix; st != null -> by rng_prefix(drop_seed, drop_stream, st->step) (graph replay)
 void launch_dense_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int relu,
-                      int dropout, uint32_t drop_prefix, uint32_t drop_thr, float drop_scale, int mode, hipStream_t s);
+                      int dropout, uint32_t drop_prefix, uint32_t drop_thr, float drop_scale, int mode, hipStream_t s,
+                      const StepState* st = nullptr, uint32_t drop_seed = 0, uint32_t drop_stream = 0);
 // dX[m][k] = sum_n dY[m][n] W[n][k]; mask != null: dX = mask > 0 ? dX * mask_scale : 0 (ReLU / dropout backward of the layer's input)
 void launch_dense_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, const float* mask, float mask_scale,
                         int mode, hipStream_t s);
@@ -100,12 +115,13 @@ void launch_dense_wgrad(const float* X, const float* dY, float* dW, float* dB, i
 // X is the resident feature tensor [N_total, H, W]; `idx` (may be null) gathers the
 // batch rows, fusing Keras' shuffle+batch gather (nsga_penalty.py:383) into the load.
 // ---------------------------------------------------------------------------
+// st (optional): the batch's first row comes from st->row0 instead of row0
 void launch_conv1_fwd(const float* X, const int32_t* idx, int64_t row0, const float* Wt, const float* bias,
-                      float* Y, int B, int H, int W, int Cout, int KS, int relu, hipStream_t s);
+                      float* Y, int B, int H, int W, int Cout, int KS, int relu, hipStream_t s, const StepState* st = nullptr);
 int conv1_wgrad_blocks(int B, int H, int W);
 // P[blk][Cout*(KS*KS) + Cout]: per-block partial kernel grads then bias grads
 void launch_conv1_wgrad(const float* X, const int32_t* idx, int64_t row0, const float* dY, float* P,
-                        int B, int H, int W, int Cout, int KS, hipStream_t s);
+                        int B, int H, int W, int Cout, int KS, hipStream_t s, const StepState* st = nullptr);
 
 // ---------------------------------------------------------------------------
 // Per-channel reductions over the M rows of an [M][C] tensor (C % 4 == 0).
@@ -160,9 +176,10 @@ void launch_gap_bwd(const float* dY, const float* X, float* dX, int B, int HW, i
 // softmax + clipped sparse CE (+ gradient wrt logits when dZ != null); adds into
 // acc[0] (double: sum of per-sample losses) and acc[1] (as int64: correct); writes preds when non-null.
 void launch_softmax_ce(const float* Z, const int32_t* labels, const int32_t* idx, int64_t row0, int B, int C,
-                       float* dZ, double* acc, int32_t* preds, hipStream_t s);
+                       float* dZ, double* acc, int32_t* preds, hipStream_t s, const StepState* st = nullptr);
+// st != null: alpha = alpha_table[st->iter] (host-precomputed per iteration: the Keras step size in double, rounded once)
 void launch_adam(float* w, const float* g, float* m, float* v, int64_t n, float alpha, float c1, float c2,
-                 float eps, hipStream_t s);
+                 float eps, hipStream_t s, const StepState* st = nullptr, const float* alpha_table = nullptr);
 // device twin of epoch_permutation (net.h): out[rank of key_i] = i; n <= EPOCH_PERMUTATION_DEVICE_MAX (O(n^2) rank sort)
 constexpr int64_t EPOCH_PERMUTATION_DEVICE_MAX = 262144;
 void launch_epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out, hipStream_t s);

@@ -114,6 +114,12 @@ class Net : public GemmHook {
 
     // fwd + bwd + Adam on rows idx[row0 .. row0+B) (idx may be null -> rows row0..)
     void train_step(const float* X, const int32_t* y, const int32_t* idx, int64_t row0, int B);
+    // The fit loop's form of the same step: the batch position, dropout counter and Adam iteration live in a device
+    // StepState (kernels.h), so a full-batch step has no per-step host arguments; with CMOOP_GRAPH=1 it is captured ONCE
+    // as a hipGraph and replayed (opt-in: measured no faster than eager launches, see begin_fit).
+    void begin_fit(int64_t total_steps);      // uploads Adam's per-iteration step sizes, zeroes the state
+    void begin_epoch();                       // state.row0 = 0
+    void train_step_stateful(const float* X, const int32_t* y, const int32_t* idx, int B);
     // inference over n rows of (X, y); returns sum of per-sample losses and #correct, fills preds (device, may be null)
     void evaluate(const float* X, const int32_t* y, int64_t n, double* loss_sum, long long* correct, int32_t* preds);
     void read_train_metrics(double* loss_sum, long long* correct, bool reset);
@@ -123,8 +129,9 @@ class Net : public GemmHook {
 
   private:
     void build_plan();
-    void forward(const float* X, const int32_t* idx, int64_t row0, int B, bool train);
-    void backward(const float* X, const int32_t* idx, int64_t row0, int B);
+    void forward(const float* X, const int32_t* idx, int64_t row0, int B, bool train, const StepState* st = nullptr);
+    void backward(const float* X, const int32_t* idx, int64_t row0, int B, const StepState* st = nullptr);
+    void step_body(const float* X, const int32_t* y, const int32_t* idx, int64_t row0, int B, const StepState* st);
     ConvGeom geom_of(const Op& op, int B) const;
     void run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e, int* stats_blocks = nullptr);
     float* dalloc(size_t floats);
@@ -140,6 +147,11 @@ class Net : public GemmHook {
     int64_t n_params_ = 0;
     float *params_ = nullptr, *grads_ = nullptr, *adam_m_ = nullptr, *adam_v_ = nullptr, *snap_ = nullptr;
     float *wgrad_ws_ = nullptr, *wd_ws_ = nullptr, *red_ws_ = nullptr, *splitk_ws_ = nullptr;
+    StepState* st_dev_ = nullptr;       // device step state (train_step_stateful)
+    float* alpha_tab_ = nullptr;        // Adam step size per iteration
+    int64_t alpha_tab_n_ = 0, host_row0_ = 0;
+    hipGraphExec_t graph_exec_ = nullptr;   // the captured full-batch train step
+    bool graph_ok_ = true;
     FlipEntry* flip_table_ = nullptr;   // device table of the conv layers whose dgrad needs flip-transposed weights
     int flip_layers_ = 0;
     int64_t flip_max_elems_ = 0;
