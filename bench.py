@@ -504,7 +504,9 @@ def main(argv=None, t_origin=None):
     if rank == 0:
         evals = n_pop * steps
         value = evals / (elapsed / 3600.0)
-        work = sum(G.eval_flops(g, variant, args.classes, T, F, n_tr, n_va, args.epochs, 1) for g in genes) * steps
+        # FLOPs actually executed: the read-out pass reuses the last epoch's validation pass (same weights, deterministic
+        # inference), so P = 0 extra inference passes here (the reference runs predict() again: P = 1)
+        work = sum(G.eval_flops(g, variant, args.classes, T, F, n_tr, n_va, args.epochs, 0) for g in genes) * steps
         if roofline is not None:   # chip-level view: all algorithmic conv/dense FLOPs of the step / wall time
             roofline["aggregate_timed_region"] = {"achieved": round(work / elapsed / 1e12 / world, 2),
                                                   "frac": round(work / elapsed / 1e12 / world / peak, 4),

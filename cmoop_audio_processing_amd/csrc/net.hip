@@ -882,8 +882,9 @@ EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Data
     try {
         // Model.fit + EarlyStopping(monitor='val_loss', patience) -- keras/src/callbacks/early_stopping.py (3.6)
         double best = INFINITY, last_val_acc = 0.0, last_val_loss = 0.0;
-        int wait = 0;
-        bool have_best = false;
+        long long last_corr = 0;
+        int wait = 0, best_epoch = -1;
+        bool have_best = false, preds_are_final = false;
         net.begin_fit((int64_t)cfg.epochs * ((ds.n_train + cfg.batch - 1) / cfg.batch));
         for (int epoch = 0; epoch < cfg.epochs; ++epoch) {
             if (cfg.shuffle && ds.n_train <= EPOCH_PERMUTATION_DEVICE_MAX) {
@@ -899,10 +900,12 @@ EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Data
             for (int64_t s = 0; s < ds.n_train; s += cfg.batch)
                 net.train_step_stateful(ds.x_train, ds.y_train, d_idx, (int)std::min<int64_t>(cfg.batch, ds.n_train - s));
             double ls; long long corr;
-            net.evaluate(ds.x_val, ds.y_val, ds.n_val, &ls, &corr, nullptr);
+            net.evaluate(ds.x_val, ds.y_val, ds.n_val, &ls, &corr, d_preds);   // keeps this epoch's predictions
             net.drain_profile();
             last_val_loss = ls / (double)ds.n_val;
             last_val_acc = (double)corr / (double)ds.n_val;
+            last_corr = corr;
+            preds_are_final = true;     // d_preds / last_val_* describe the weights the net holds right now
             res.epochs_run = epoch + 1;
             if (!cfg.early_stop) continue;
             if (cfg.restore_best && !have_best) { net.snapshot_params(); have_best = true; }
@@ -910,15 +913,22 @@ EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Data
             if (last_val_loss < best) {
                 best = last_val_loss;
                 if (cfg.restore_best) net.snapshot_params();
+                best_epoch = epoch;
                 wait = 0;
                 continue;
             }
             if (wait >= cfg.patience && epoch > 0) break;
         }
-        if (cfg.early_stop && cfg.restore_best && have_best) net.restore_snapshot();
-        // readouts: model.evaluate / model.predict + argmax + confusion matrix (one pass yields both)
-        double ls; long long corr;
-        net.evaluate(ds.x_val, ds.y_val, ds.n_val, &ls, &corr, d_preds);
+        if (cfg.early_stop && cfg.restore_best && have_best && best_epoch != res.epochs_run - 1) {
+            net.restore_snapshot();      // weights of an earlier epoch: the last pass's predictions no longer apply
+            preds_are_final = false;
+        }
+        // readouts: model.evaluate / model.predict + argmax + confusion matrix (one inference pass yields both).  When
+        // the net still holds the weights of its last epoch, that epoch's validation pass IS this pass (inference is
+        // deterministic): its loss, accuracy and predictions are reused instead of recomputing N_val forward passes.
+        double ls = last_val_loss * (double)ds.n_val;
+        long long corr = last_corr;
+        if (!preds_are_final) net.evaluate(ds.x_val, ds.y_val, ds.n_val, &ls, &corr, d_preds);
         res.val_loss = cfg.acc_readout == 0 ? last_val_loss : ls / (double)ds.n_val;
         res.acc = cfg.acc_readout == 0 ? last_val_acc : (double)corr / (double)ds.n_val;
         launch_confusion(ds.y_val, d_preds, ds.n_val, cfg.classes, cfg.fpr_variant == 1, d_cm, stream);
