@@ -529,9 +529,13 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             }
         continue;
     }
-    float csum[CT], csq[CT];
+    float csum[CT], csq[CT], bias_v[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) { csum[ct] = 0.f; csq[ct] = 0.f; }
+    for (int ct = 0; ct < CT; ++ct) {
+        csum[ct] = 0.f; csq[ct] = 0.f;
+        const int col = n0 + wcol + ct * 16 + lr;
+        bias_v[ct] = (e.bias && col < N) ? e.bias[col] : 0.f;    // once per column, not once per stored element
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -550,8 +554,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             for (int ct = 0; ct < CT; ++ct) {
                 const int col = n0 + wcol + ct * 16 + lr;
                 if (col >= N) continue;
-                float v = acc[rt][ct][r];
-                if (e.bias) v += e.bias[col];
+                float v = acc[rt][ct][r] + bias_v[ct];
                 if (e.relu) v = fmaxf(v, 0.f);
                 const size_t off = rbase + col;
                 if (e.dropout) {
@@ -809,6 +812,7 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     if (e.stats) *stats_blocks = cdiv(g.M, bm);
     // many-wave grids of 128x64 tiles run 3-4 % faster with 16-deep K chunks (half the LDS, 4-5 workgroups
     // per CU instead of 2); single-wave grids prefer the 32-deep chunk (half the barriers)
+    // (measured: 16-deep chunks for the 128x128 tile -- three workgroups per CU -- 124 vs 130 TFLOP/s: not used)
     const bool bk32_tile = mode != GEMM_FP32 ||
                            (bk32 && !(bm == 128 && bn == 64 && splits == 1 && !balanced_wgs && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024));
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \
