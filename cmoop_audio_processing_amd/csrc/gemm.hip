@@ -888,7 +888,8 @@ template <int BCO, int BKI>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                           float* __restrict__ P, GeomDev g, int rows_per_slice,
                                                           float* __restrict__ Pbias, size_t slab_stride,
-                                                          const uint2* __restrict__ rowtab, int tab_rows) {
+                                                          const uint2* __restrict__ rowtab, int tab_rows, int grouped_kt,
+                                                          int grouped_ct, int grouped_slices) {
     constexpr int MC = 32;
     constexpr int LDX = BKI + 16;                          // == 16 mod 32
     constexpr int LDY = (BCO == 16) ? 16 : BCO + 16;
@@ -903,8 +904,21 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float Ys[2][MC * LDY];
 
     const int t = threadIdx.x;
-    const int k0 = blockIdx.x * BKI, co0 = blockIdx.y * BCO;
-    const int mbeg = blockIdx.z * rows_per_slice;
+    // XCD-grouped 1-D grid (grouped_kt > 0): workgroups are dealt round-robin over the 8 XCDs, so linear id L runs on
+    // XCD L & 7; all K / co tiles of one row slice are given to ONE XCD (slice = 8 * group + xcd) and the slice count is
+    // chosen so that each XCD's share fills whole waves of its 64 workgroup slots.  The dY slice and the input rows a
+    // slice gathers are then fetched into one L2 instead of eight (fabric reads of 64->64 k5 @101x40: 1.1 GB -> see DESIGN).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (grouped_kt > 0) {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int per = grouped_kt * grouped_ct;
+        const int grp = j / per, r = j - grp * per;
+        by = r / grouped_kt; bx = r - by * grouped_kt;
+        bz = grp * 8 + xcd;
+        if (bz >= grouped_slices) return;
+    }
+    const int k0 = bx * BKI, co0 = by * BCO;
+    const int mbeg = bz * rows_per_slice;
     const int mend = min(g.M, mbeg + rows_per_slice);
 
     // X gather: this thread owns k index k0 + 4*xq for rows xrow + p*RPPX (fixed over the block's life)
@@ -1001,7 +1015,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
         for (int j = 0; j < KPW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // bias gradient (column sums of dY) rides along in the blocks of the first K tile
-    const bool do_bias = Pbias != nullptr && blockIdx.x == 0;
+    const bool do_bias = Pbias != nullptr && bx == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const int nchunks = (mend > mbeg) ? (mend - mbeg + MC - 1) / MC : 0;
     if (nchunks > 0) {
@@ -1062,10 +1076,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
             const int q4 = t >> 2, j = t & 3;
             float sacc = 0.f;
             for (int r = 0; r < RPPY; ++r) sacc += red[4 * (r * TPRY + q4) + j];
-            Pbias[(size_t)blockIdx.z * slab_stride + co0 + t] = sacc;
+            Pbias[(size_t)bz * slab_stride + co0 + t] = sacc;
         }
     }
-    float* Pout = P + (size_t)blockIdx.z * slab_stride;
+    float* Pout = P + (size_t)bz * slab_stride;
 #pragma unroll
     for (int c2 = 0; c2 < CPW; ++c2)
 #pragma unroll
@@ -1241,10 +1255,41 @@ static inline int wgrad_bki(int M, int N, int K) {
     return blocks >= 1024 ? 128 : 64;
 }
 
+// XCD-grouped wgrad grid: OFF by default.  Measured round 2 (after the row-table loader, slice count chosen per XCD so
+// that every XCD's share fills whole waves): 96 vs 108 TFLOP/s on 64->64 k5 @101x40, 106 vs 131 on 256->256 @26x10,
+// 96 vs 121 on 64->128 @51x20 -- slower on every shape, as in round 1: the fabric-side re-reads (6x algorithmic on the
+// 64-column layer) are served by the Infinity Cache and are not what limits the kernel; eight XCDs each hammering one
+// slice's lines are.  CMOOP_WGRAD_XCD=1 enables it for experiments.
+static bool wgrad_xcd_grouped() {
+    static const bool v = [] { const char* e = std::getenv("CMOOP_WGRAD_XCD"); return e && e[0] == '1'; }();
+    return v;
+}
+
 int wgrad_slices(const ConvGeom& g) {
     const int M = g.M(), K = g.K(), N = g.Cout;
     const int bco = wgrad_bco(N);
     const int tiles = cdiv(K, wgrad_bki(M, N, K)) * cdiv(N, bco);
+    if (wgrad_xcd_grouped() && resolve_mode(GEMM_DEFAULT) == GEMM_FP32 && M / 256 >= 8) {
+        // XCD-grouped grid: S = 8 G, each XCD runs G * tiles workgroups on its 32 CUs: choose the G whose last wave of
+        // co-resident workgroups (LDS-limited occupancy) is >= 90 % full, within the slab budget and >= 256 rows per slice
+        const int bki = wgrad_bki(M, N, K);
+        const int lds_bytes = 2 * 32 * ((bki + 16) + (bco == 16 ? 16 : bco + 16)) * 4;
+        const int slots = 32 * std::max(1, std::min(8, (160 * 1024) / lds_bytes));
+        const int64_t nk = (int64_t)N * K;
+        const int cap = (int)std::max<int64_t>(8, (16ll << 20) / std::max<int64_t>(nk, 1));
+        const int maxG = std::max(1, std::min(std::min(cap, M / 256) / 8, 64));
+        const int wantG = std::max(1, std::min(maxG, cdiv(2048, tiles * 8)));      // aim at >= ~2048 workgroups chip-wide
+        int best = wantG;
+        double best_u = -1.0;
+        for (int G = wantG; G <= maxG && G <= 2 * wantG + 4; ++G) {
+            const long blocks = (long)G * tiles;
+            const long waves = (blocks + slots - 1) / slots;
+            const double u = (double)blocks / (double)(waves * slots);
+            if (u >= 0.90) { best = G; best_u = u; break; }
+            if (u > best_u) { best_u = u; best = G; }
+        }
+        return 8 * best;
+    }
     int S = cdiv((int)(2048 * par_scale()), tiles);
     // cap the slab traffic (S*N*K floats written and read back): at most ~16M floats, but keep >= 8 slices
     const int64_t nk = (int64_t)N * K;
@@ -1281,6 +1326,11 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     // fp32-accurate choice there.  (GEMM_BF16 must round everywhere to stay consistent with its definition.)
     if (mode == GEMM_BF16X3 && bco < 128) mode = GEMM_FP32;
     dim3 grid(cdiv(g.K, bki), cdiv(N, bco), S);
+    int gkt = 0, gct = 0;
+    if (wgrad_xcd_grouped() && mode == GEMM_FP32 && S >= 8) {
+        gkt = (int)grid.x; gct = (int)grid.y;
+        grid = dim3((unsigned)(cdiv(S, 8) * 8 * gkt * gct), 1, 1);
+    }
     // the row table must cover every row a chunk can touch (rows are consumed 32 at a time)
     const uint2* rt = (rowtab && tab_rows >= cdiv(g.M, 32) * 32 && g.KH * g.KW <= 32) ? static_cast<const uint2*>(rowtab) : nullptr;
 #define CMOOP_WGK(KERNEL)                                                                                       \
@@ -1296,10 +1346,10 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
 #define CMOOP_WGF(KERNEL)                                                                                       \
     do {                                                                                                       \
         if (tm && tm->start && tm->ext) {                                                                      \
-            hipExtLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps, Pbias, stride, rt, tab_rows); \
+            hipExtLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, dY, P, g, rps, Pbias, stride, rt, tab_rows, gkt, gct, S); \
         } else {                                                                                               \
             if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));                                      \
-            hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, X, dY, P, g, rps, Pbias, stride, rt, tab_rows);   \
+            hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, X, dY, P, g, rps, Pbias, stride, rt, tab_rows, gkt, gct, S);   \
             if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));                                       \
         }                                                                                                      \
     } while (0)
