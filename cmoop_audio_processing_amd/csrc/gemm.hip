@@ -316,15 +316,16 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         else load_chunk_slow(c, ra, rb);
     };
     auto store_chunk = [&](int buf, const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
+        // (the row guards are compile-time true whenever the passes tile the block exactly: no exec-mask branches then)
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
             int ml = lrow + p * RPP;
-            if (ml < BM) *reinterpret_cast<f32x4*>(&As[buf][ml * LDK + 4 * kq]) = ra[p];
+            if (APASS * RPP == BM || ml < BM) *reinterpret_cast<f32x4*>(&As[buf][ml * LDK + 4 * kq]) = ra[p];
         }
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             int nl = lrow + p * RPP;
-            if (nl < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nl * LDK + 4 * kq]) = rb[p];
+            if (BPASS * RPP == BN || nl < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nl * LDK + 4 * kq]) = rb[p];
         }
     };
 
@@ -813,6 +814,7 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     // many-wave grids of 128x64 tiles run 3-4 % faster with 16-deep K chunks (half the LDS, 4-5 workgroups
     // per CU instead of 2); single-wave grids prefer the 32-deep chunk (half the barriers)
     // (measured: 16-deep chunks for the 128x128 tile -- three workgroups per CU -- 124 vs 130 TFLOP/s: not used)
+    // (measured again with the r2 loader: 32-deep chunks on the >= 1024-tile 128x64 grids 119 vs 123 TFLOP/s: 16 stays)
     const bool bk32_tile = mode != GEMM_FP32 ||
                            (bk32 && !(bm == 128 && bn == 64 && splits == 1 && !balanced_wgs && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024));
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \

@@ -33,8 +33,9 @@ def main():
     ap.add_argument("--trace", default="", help="write a JSON trace: per evaluate call wall-clock, epochs run, hypervolume")
     ap.add_argument("--compute", default="fp32", choices=["fp32", "bf16x3", "bf16"])
     ap.add_argument("--hard", action="store_true",
-                    help="hypervolume runs: -10 dB SNR and neighbouring classes share two of three partials, so accuracies spread "
-                         "(~0.6-0.95, like the reference's published Pareto range) instead of saturating at 1.0")
+                    help="hypervolume runs: low SNR (--snr-db) and neighbouring classes share two of three partials, so accuracies "
+                         "spread (like the reference's published Pareto range) instead of saturating at 1.0")
+    ap.add_argument("--snr-db", type=float, default=-17.0, help="SNR of the --hard set")
     ap.add_argument("--fpr", default="v1_quirk", choices=["v1_quirk", "v1", "v3"],
                     help="v1_quirk = nsga_penalty.py:387 (y_true all zeros: FPR <= 1/C, constraint g3 inactive); v1 = every other script")
     a = ap.parse_args()
@@ -44,7 +45,7 @@ def main():
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
-    wav, y = synth_waveforms(a.clips, 10, 1234, dev, hard=a.hard)
+    wav, y = synth_waveforms(a.clips, 10, 1234, dev, hard=a.hard, hard_snr_db=a.snr_db)
     feats = frontend.log_mel(wav)
     n_tr, n_va = int(a.clips * 0.8), int(a.clips * 0.1)
     Xtr, Xva = feats[:n_tr].contiguous(), feats[n_tr:n_tr + n_va].contiguous()

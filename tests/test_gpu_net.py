@@ -540,6 +540,37 @@ def test_hypervolume_parity_gpu_vs_oracle_search():
         assert abs(hv_g - hv_c) <= 0.01 * max(hv_c, 1e-12)
 
 
+def test_hypervolume_parity_on_the_hard_synthetic_set():
+    """on the §8d synthetic set every candidate scores accuracy 1.0, so 'HV within 1 %' could not fail.
+    The same search (pop 4, 2 generations, early stopping on) on the HARD variant of the set -- low SNR, neighbouring
+    classes share two of three partials (bench.synth_waveforms(hard=True)) -- through the real pipeline: HIP front end ->
+    StandardScaler -> GPU evaluator, against the oracle on the same features.  Accuracies spread; gate: hypervolume
+    within 1 % on one shared reference point, widened only to the oracle's own spread between torch's two conv algorithms."""
+    import bench
+    from cmoop_audio_processing_amd import frontend, nsga
+    wav, y = bench.synth_waveforms(480, 10, 7, torch.device("cuda"), n_samples=4000, chunk=160, hard=True, hard_snr_db=-6.0)
+    feats = frontend.log_mel(wav)                                   # [480, 26, 40]
+    Xtr_d, Xva_d = feats[:320].contiguous(), feats[320:].contiguous()
+    frontend.prepare_dataset(Xtr_d, Xva_d, None, mode="refit")
+    Xtr, Xva = Xtr_d.cpu().numpy(), Xva_d.cpu().numpy()
+    ytr, yva = y[:320].cpu().numpy(), y[320:].cpu().numpy()
+    cfg = EvalConfig.preset("nsga_penalty", epochs=12, patience=2, batch=32, eval_batch=64, seed=3, n_slots=4, fpr_variant="v1")
+    ev = PopulationEvaluator(Xtr_d, y[:320], Xva_d, y[320:], cfg)
+    _, hist_gpu = nsga.nsga2(ev.compute_objectives_and_constraints, 4, 2, seed=5)
+    _, hist_cpu = nsga.nsga2(_oracle_population_evaluator(cfg, Xtr, ytr, Xva, yva), 4, 2, seed=5)
+    with torch.backends.mkldnn.flags(enabled=False):
+        _, hist_cpu2 = nsga.nsga2(_oracle_population_evaluator(cfg, Xtr, ytr, Xva, yva), 4, 2, seed=5)
+    fr = lambda hist: [[[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in h] for h in hist]
+    f_gpu, f_cpu, f_cpu2 = fr(hist_gpu), fr(hist_cpu), fr(hist_cpu2)
+    accs = sorted(r["Accuracy"] for r in hist_gpu[-1])
+    print("hard set, last generation accuracies (gpu):", accs)
+    ref = nsga.shared_reference_point(f_gpu + f_cpu + f_cpu2)
+    for g in range(2):
+        hv_g, hv_c, hv_c2 = (nsga.hypervolume(f[g], ref) for f in (f_gpu, f_cpu, f_cpu2))
+        print(f"gen {g}: HV gpu {hv_g:.6f} oracle {hv_c:.6f} oracle(native conv) {hv_c2:.6f}")
+        assert min(abs(hv_g - hv_c), abs(hv_g - hv_c2)) <= max(0.01 * max(hv_c, 1e-12), abs(hv_c - hv_c2)) + 1e-15
+
+
 def _cos(a, b):
     a, b = a.astype(np.float64), b.astype(np.float64)
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
