@@ -157,13 +157,21 @@ template <int BM, int BN, int BK, int WM, int MODE = 0>   // MODE: GEMM_FP32 exa
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                         float* __restrict__ Y, GeomDev g, EpiDev e,
                                                         float* __restrict__ slab, int chunks_per_split) {
-    static_assert(MODE == GEMM_FP32 || MODE == GEMM_BF16X3 || MODE == GEMM_BF16, "unknown GEMM mode");
-    constexpr bool PLANES = MODE != GEMM_FP32;
+    static_assert(MODE == GEMM_FP32 || MODE == GEMM_FP32_DMA || MODE == GEMM_BF16X3 || MODE == GEMM_BF16, "unknown GEMM mode");
+    constexpr bool PLANES = MODE == GEMM_BF16X3 || MODE == GEMM_BF16;
+    // GEMM_FP32_DMA: exact fp32 MFMA with the operands brought global -> LDS by the LDS-DMA path (buffer_load_dwordx4 ... lds,
+    // 16 bytes per lane: new on gfx950) -- no register staging, no ds_write, no vmcnt wait in front of an LDS store.
+    constexpr bool DMA = MODE == GEMM_FP32_DMA;
+    static_assert(!DMA || (BK == 32 && BM % 32 == 0 && BN % 32 == 0), "LDS-DMA image: 32-deep chunks, whole 8-row wave stripes");
     constexpr bool PIPE = false;   // software-pipelined main loop (see below): measured, no gain (it halves the global-load landing time)
     constexpr bool DIST2 = !PLANES && BM <= 64;   // two-chunk-deep global prefetch (two register sets); on 128-row tiles it costs the second workgroup per CU (measured 104 vs 124 TFLOP/s)
     constexpr int NP = MODE == GEMM_BF16X3 ? 3 : 1;
     constexpr int WN = 4 / WM;
-    constexpr int LDK = BK + 8;    // pitch = 2 (mod 4) sixteen-byte slots: conflict-free ds_read_b128 fragments (16-lane groups, 64 banks)
+    // register-staged image: pitch BK + 8 floats = 2 (mod 4) sixteen-byte slots: conflict-free ds_read_b128 fragments (16-lane
+    // groups, 64 banks).  LDS-DMA image: a wave instruction lands 64 lanes x 16 B CONTIGUOUSLY (8 rows x 128 B), so rows
+    // are unpadded (pitch 32 floats) and the sixteen-byte slot of a row is XOR-swizzled with the row's low 3 bits on the
+    // SOURCE side (lane l fetches global slot (l & 7) ^ (l >> 3)); fragment reads undo it: conflict-free as well.
+    constexpr int LDK = DMA ? BK : BK + 8;
     constexpr int TPR = BK / 4;
     constexpr int RPP = 256 / TPR;
     constexpr int APASS = (BM + RPP - 1) / RPP;
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     if (fast) {
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
-            a_voff[p] = ((uint32_t)((a_base[p] + a_ih0[p] * g.W + a_iw0[p]) << g.cshift) + x_bias + 4 * kq) * 4u;
+            a_voff[p] = ((uint32_t)((a_base[p] + a_ih0[p] * g.W + a_iw0[p]) << g.cshift) + x_bias + 4 * (DMA ? (kq ^ (lrow & 7)) : kq)) * 4u;
             // valid kh / kw form contiguous ranges: [max(0,-ih0), min(KH, H-ih0)) x [max(0,-iw0), min(KW, W-iw0))
             const int hlo = max(0, -a_ih0[p]), hhi = min(g.KH, g.H - a_ih0[p]);
             const int wlo = max(0, -a_iw0[p]), whi = min(g.KW, g.W - a_iw0[p]);
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             const int nl = lrow + p * RPP, n = n0 + nl;
-            b_voff[p] = (nl < BN && n < g.Cout) ? (uint32_t)(n * g.K + 4 * kq) * 4u : 0xFFFFFFF0u;
+            b_voff[p] = (nl < BN && n < g.Cout) ? (uint32_t)(n * g.K + 4 * (DMA ? (kq ^ (lrow & 7)) : kq)) * 4u : 0xFFFFFFF0u;
         }
     }
     auto load_chunk_fast = [&](int c, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
@@ -290,6 +298,27 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int p = 0; p < BPASS; ++p)
             rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)b_voff[p], b_soff, 0));
+    };
+    // LDS-DMA: chunk c straight into LDS image `buf` (out-of-range lanes land zeros: probed on gfx950, tools/debug/lds_dma_probe.hip)
+    auto dma_chunk = [&](int c, int buf) {
+        if constexpr (DMA) {
+            const int k0 = c * BK;
+            const int tap = k0 >> g.cshift, ci0 = k0 & (g.Cin - 1);
+            const int kh = (tap * g.rcp_kw) >> 16, kw = tap - kh * g.KW;
+            const int a_soff = ((((kh * g.W + kw) << g.cshift) + ci0) * 4);
+            const int b_soff = k0 * 4;
+            const int wv = __builtin_amdgcn_readfirstlane(t >> 6);          // wave-uniform LDS base (goes to M0)
+#pragma unroll
+            for (int p = 0; p < APASS; ++p) {
+                const uint32_t dead = (uint32_t)__builtin_amdgcn_sbfe((int)a_inv[p], tap, 1);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)&As[buf][(p * RPP + 8 * wv) * LDK], 16,
+                                                         (int)(a_voff[p] | dead), a_soff, 0, 0);
+            }
+#pragma unroll
+            for (int p = 0; p < BPASS; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)&Bs[buf][(p * RPP + 8 * wv) * LDK], 16,
+                                                         (int)b_voff[p], b_soff, 0, 0);
+        }
     };
     auto load_chunk_slow = [&](int c, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
         const int kidx = c * BK + 4 * kq;
@@ -395,10 +424,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             f32x4 a[RT], b[CT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
-                a[rt] = *reinterpret_cast<const f32x4*>(&As[buf][(wrow + rt * 16 + lr) * LDK + kk * 16 + q * 4]);
+                a[rt] = *reinterpret_cast<const f32x4*>(&As[buf][(wrow + rt * 16 + lr) * LDK + (DMA ? (((kk * 4 + q) ^ (lr & 7)) * 4) : kk * 16 + q * 4)]);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
-                b[ct] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wcol + ct * 16 + lr) * LDK + kk * 16 + q * 4]);
+                b[ct] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wcol + ct * 16 + lr) * LDK + (DMA ? (((kk * 4 + q) ^ (lr & 7)) * 4) : kk * 16 + q * 4)]);
             // raised priority over the MFMA burst: the co-resident wave's address VALU no longer wins
             // issue arbitration against it (+3..6 % measured, same-box A/B)
             __builtin_amdgcn_s_setprio(1);
@@ -442,6 +471,19 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
             compute(1);
             if (c + 2 < nchunks) store_chunk(0, ra0, rb0);
+            __syncthreads();
+        }
+    } else if constexpr (DMA) {
+        // operands go global -> LDS directly: chunk c + 1 lands in the other image while chunk c is multiplied; the only
+        // wait is vmcnt(0) in front of the barrier that publishes it
+        dma_chunk(cbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int c = cbeg; c < nchunks; ++c) {
+            const int buf = (c - cbeg) & 1;
+            if (c + 1 < nchunks) dma_chunk(c + 1, buf ^ 1);
+            compute(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     } else if constexpr (BK == 32 && PIPE) {
@@ -817,10 +859,17 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     // (measured again with the r2 loader: 32-deep chunks on the >= 1024-tile 128x64 grids 119 vs 123 TFLOP/s: 16 stays)
     const bool bk32_tile = mode != GEMM_FP32 ||
                            (bk32 && !(bm == 128 && bn == 64 && splits == 1 && !balanced_wgs && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024));
+    // LDS-DMA operand path: needs the chunk-in-one-tap condition of the fast loader and <= 32 taps.  Measured per tile
+    // (isolated, forward / dgrad TFLOP/s, DMA vs register staging): 128x32 (32-column layers @101x40) 101 / 109 vs 90 / 95
+    // -> used; 128x128 130 vs 132, 128x64 @51x20 111 vs 116, 64->128 dgrad 116 vs 123 -> not used (the DMA fill rate per
+    // wave is the limit once a tile needs four or more 1 KiB fills per operand and chunk).
+    static const int dma_env = [] { const char* v = std::getenv("CMOOP_DMA"); return v ? std::atoi(v) : 1; }();
+    const bool use_dma = dma_env && mode == GEMM_FP32 && (g.Cin % 32 == 0) && g.KH * g.KW <= 32;
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \
     do {                                                                                      \
         if (mode == GEMM_BF16X3) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16X3>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);   \
         else if (mode == GEMM_BF16) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);  \
+        else if (bk32_tile && use_dma && BM_ == 128 && BN_ == 32) launch_fwd_t<BM_, 32, 32, WM_, GEMM_FP32_DMA>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);   \
         else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);   \
         else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);        \
     } while (0)
