@@ -385,18 +385,18 @@ int cmoop_conv_time(int32_t mode, const float* x, const float* w, const float* b
             gd.H = g.OH; gd.W = g.OW; gd.Cin = Cout; gd.Cout = Cin; gd.OH = g.H; gd.OW = g.W;
             gd.pad_t = KS - 1 - g.pad_t; gd.pad_l = KS - 1 - g.pad_l;
         }
-        void* tab = nullptr;
-        const int tab_rows = (mode == 2 && KS * KS <= 32) ? rowtab_rows(g) : 0;
+        void* tab = nullptr;   // the layer's row table, as the trainer passes it (forward / wgrad: forward geometry; dgrad: its own)
+        const int tab_rows = (KS * KS <= 32 && Cin >= 16) ? rowtab_rows(mode == 1 ? gd : g) : 0;
         if (mode == 2) CMOOP_HIP(hipMalloc(&wg, (size_t)S * g.Cout * g.K() * 4));
         if (tab_rows) {
             CMOOP_HIP(hipMalloc(&tab, (size_t)tab_rows * 8));
-            launch_build_rowtab(g, tab, s);
+            launch_build_rowtab(mode == 1 ? gd : g, tab, s);
         }
         const size_t skf = mode == 0 ? igemm_splitk_workspace(g) : (mode == 1 ? igemm_splitk_workspace(gd) : 0);
         if (skf) CMOOP_HIP(hipMalloc(&sk, skf * 4));
         auto once = [&]() {
-            if (mode == 0) launch_igemm_fwd(x, w, y, g, e, s, nullptr, sk, skf);
-            else if (mode == 1) launch_igemm_fwd(y, wd, const_cast<float*>(x), gd, e, s, nullptr, sk, skf);
+            if (mode == 0) launch_igemm_fwd(x, w, y, g, e, s, nullptr, sk, skf, nullptr, tab, tab_rows);
+            else if (mode == 1) launch_igemm_fwd(y, wd, const_cast<float*>(x), gd, e, s, nullptr, sk, skf, nullptr, tab, tab_rows);
             else launch_igemm_wgrad(x, y, wg, g, S, s, nullptr, nullptr, 0, GEMM_DEFAULT, tab, tab_rows);
         };
         for (int i = 0; i < 3; ++i) once();

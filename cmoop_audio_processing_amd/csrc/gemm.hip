@@ -156,7 +156,8 @@ static GeomDev to_dev(const ConvGeom& g) {
 template <int BM, int BN, int BK, int WM, int MODE = 0>   // MODE: GEMM_FP32 exact fp32 MFMA, GEMM_BF16X3 / GEMM_BF16 bf16 planes
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                         float* __restrict__ Y, GeomDev g, EpiDev e,
-                                                        float* __restrict__ slab, int chunks_per_split) {
+                                                        float* __restrict__ slab, int chunks_per_split,
+                                                        const uint2* __restrict__ rowtab, int tab_rows) {
     static_assert(MODE == GEMM_FP32 || MODE == GEMM_FP32_DMA || MODE == GEMM_BF16X3 || MODE == GEMM_BF16, "unknown GEMM mode");
     constexpr bool PLANES = MODE == GEMM_BF16X3 || MODE == GEMM_BF16;
     // GEMM_FP32_DMA: exact fp32 MFMA with the operands brought global -> LDS by the LDS-DMA path (buffer_load_dwordx4 ... lds,
@@ -231,7 +232,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     const int m0 = mtile * BM;
     const int n0 = ntile * BN;
 
-    // per-pass row decode (fixed over the K loop)
+    // per-pass row decode (fixed over the K loop); with the layer's row table (the trainer's forward launches) the fast
+    // loader's per-row offset and padding mask are two table words instead of two divisions and ~40 VALU per row
+    const bool fast_geom = (g.Cin & (BK - 1)) == 0 && g.KH * g.KW <= 32;
+    const bool use_tab = fast_geom && rowtab != nullptr && m0 + BM <= tab_rows;
     int a_ih0[APASS], a_iw0[APASS], a_base[APASS];
     bool a_ok[APASS];
 #pragma unroll
@@ -239,12 +243,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         int ml = lrow + p * RPP;
         int m = m0 + ml;
         a_ok[p] = ml < BM && m < g.M;
-        int mm = a_ok[p] ? m : 0;
-        int b = fastdiv(mm, g.ohw_magic, g.ohw_shift), r = mm - b * g.OHW;
-        int oh = fastdiv(r, g.ow_magic, g.ow_shift), ow = r - oh * g.OW;
-        a_ih0[p] = oh * g.stride - g.pad_t;
-        a_iw0[p] = ow * g.stride - g.pad_l;
-        a_base[p] = b * g.H * g.W;
+        a_ih0[p] = a_iw0[p] = a_base[p] = 0;
+        if (!use_tab) {
+            int mm = a_ok[p] ? m : 0;
+            int b = fastdiv(mm, g.ohw_magic, g.ohw_shift), r = mm - b * g.OHW;
+            int oh = fastdiv(r, g.ow_magic, g.ow_shift), ow = r - oh * g.OW;
+            a_ih0[p] = oh * g.stride - g.pad_t;
+            a_iw0[p] = ow * g.stride - g.pad_l;
+            a_base[p] = b * g.H * g.W;
+        }
     }
 
     // two register sets: the loads of chunk c+2 are issued before chunk c is computed and are
@@ -258,13 +265,21 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     // ONCE (voffset), the chunk's tap / channel offset on the scalar unit (soffset), and SAME-padding handled by a
     // precomputed per-row bitmask of invalid taps that turns the voffset out of range (the hardware range check then
     // returns zeros): 2 VALU per A load, 0 per B load.
-    const bool fast = (g.Cin & (BK - 1)) == 0 && g.KH * g.KW <= 32;
+    const bool fast = fast_geom;
     const uint32_t x_bias = (uint32_t)((g.pad_t * g.W + g.pad_l) << g.cshift);          // floats: makes every row offset >= 0
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(X) - x_bias, 0, (int)(((uint32_t)g.B * g.H * g.W << g.cshift) + x_bias) * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, g.Cout * g.K * 4, 0x00020000);
     uint32_t a_voff[APASS], a_inv[APASS], b_voff[BPASS];
-    if (fast) {
+    if (use_tab) {
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            const int ml = lrow + p * RPP;
+            const uint2 te = rowtab[m0 + (ml < BM ? ml : 0)];
+            a_voff[p] = te.x + 16u * (uint32_t)(DMA ? (kq ^ (lrow & 7)) : kq);
+            a_inv[p] = a_ok[p] ? te.y : 0xFFFFFFFFu;
+        }
+    } else if (fast) {
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
             a_voff[p] = ((uint32_t)((a_base[p] + a_ih0[p] * g.W + a_iw0[p]) << g.cshift) + x_bias + 4 * (DMA ? (kq ^ (lrow & 7)) : kq)) * 4u;
@@ -277,6 +292,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
                 if (kh >= hlo && kh < hhi) okm |= wmask << (kh * g.KW);
             a_inv[p] = a_ok[p] ? ~okm : 0xFFFFFFFFu;
         }
+    }
+    if (fast) {
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             const int nl = lrow + p * RPP, n = n0 + nl;
@@ -702,7 +719,8 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
 
 template <int BM, int BN, int BK, int WM, int MODE = 0>
 static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDev& g, const EpiDev& e_in, hipStream_t s,
-                         const GemmTiming* tm, float* slab, int splits, int balanced_wgs = 0) {
+                         const GemmTiming* tm, float* slab, int splits, int balanced_wgs = 0, const uint2* rowtab = nullptr,
+                         int tab_rows = 0) {
     EpiDev e = e_in;
     dim3 grid(cdiv(g.M, BM), cdiv(g.Cout, BN), splits);
     const int nchunks = cdiv(g.K, BK);
@@ -720,10 +738,10 @@ static void launch_fwd_t(const float* X, const float* Wt, float* Y, const GeomDe
     }
     if (tm && tm->start && tm->ext) {
         hipExtLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM, MODE>), grid, dim3(256), 0, s, tm->start, tm->stop, 0, X, Wt, Y, g,
-                              e, sl, cps);
+                              e, sl, cps, rowtab, tab_rows);
     } else {
         if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));
-        hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM, MODE>), grid, dim3(256), 0, s, X, Wt, Y, g, e, sl, cps);
+        hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, BK, WM, MODE>), grid, dim3(256), 0, s, X, Wt, Y, g, e, sl, cps, rowtab, tab_rows);
         if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));
     }
     CMOOP_HIP(hipGetLastError());
@@ -832,8 +850,10 @@ size_t igemm_splitk_workspace(const ConvGeom& g) {
 }
 
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& cg, const GemmEpilogue& ep,
-                     hipStream_t s, const GemmTiming* tm, float* splitk_ws, size_t splitk_ws_floats, int* stats_blocks) {
+                     hipStream_t s, const GemmTiming* tm, float* splitk_ws, size_t splitk_ws_floats, int* stats_blocks,
+                     const void* rowtab_v, int tab_rows) {
     if (stats_blocks) *stats_blocks = 0;
+    const uint2* rowtab = static_cast<const uint2*>(rowtab_v);
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
     EpiDev e;
@@ -867,11 +887,11 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     const bool use_dma = dma_env && mode == GEMM_FP32 && (g.Cin % 32 == 0) && g.KH * g.KW <= 32;
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \
     do {                                                                                      \
-        if (mode == GEMM_BF16X3) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16X3>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);   \
-        else if (mode == GEMM_BF16) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);  \
-        else if (bk32_tile && use_dma && BM_ == 128 && BN_ == 32) launch_fwd_t<BM_, 32, 32, WM_, GEMM_FP32_DMA>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);   \
-        else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs);   \
-        else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits);        \
+        if (mode == GEMM_BF16X3) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16X3>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);   \
+        else if (mode == GEMM_BF16) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);  \
+        else if (bk32_tile && use_dma && BM_ == 128 && BN_ == 32) launch_fwd_t<BM_, 32, 32, WM_, GEMM_FP32_DMA>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);   \
+        else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);   \
+        else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, 0, rowtab, tab_rows);        \
     } while (0)
     // (Measured, not adopted: 256x64 tiles for the 64-column layers at 101x40 -- 109.6 vs 118.5 TFLOP/s forward.)
     if (bm == 128) {
@@ -924,7 +944,7 @@ __global__ __launch_bounds__(256) void build_rowtab_kernel(GeomDev g, uint2* __r
     tab[m] = make_uint2(((uint32_t)(((b * g.H + ih0) * g.W + iw0) << g.cshift) + bias) * 4u, ~okm);
 }
 
-int rowtab_rows(const ConvGeom& g) { return cdiv(g.M(), 32) * 32; }
+int rowtab_rows(const ConvGeom& g) { return cdiv(g.M(), 256) * 256; }   // whole 256-row tiles: padding rows are marked all-taps-invalid
 
 void launch_build_rowtab(const ConvGeom& cg, void* tab, hipStream_t s) {
     GeomDev g = to_dev(cg);

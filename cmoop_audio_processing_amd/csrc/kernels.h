@@ -53,9 +53,12 @@ struct GemmTiming {
 // returns the instantiation code mode*1e8 + BM*100000 + BN*100 + BK of the kernel that was launched
 // splitk_ws (optional, >= igemm_splitk_workspace(g) floats): lets under-filled grids split the K axis
 // stats_blocks (with e.stats): receives the number of M-tile partials written, 0 when the launch was split-K (no fused statistics)
+// rowtab / tab_rows (optional): the row table of THIS geometry (launch_build_rowtab), covering at least every 128-row tile
+// the launch touches: the kernel then reads each row's offset / padding mask instead of deriving them
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& g,
                      const GemmEpilogue& e, hipStream_t s, const GemmTiming* tm = nullptr,
-                     float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, int* stats_blocks = nullptr);
+                     float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, int* stats_blocks = nullptr,
+                     const void* rowtab = nullptr, int tab_rows = 0);
 size_t igemm_splitk_workspace(const ConvGeom& g);
 
 // dWt[n][k] = sum_m dY[m][n] * im2col(X)[m][k], split over S row-slices into P[S][N][K].

@@ -51,9 +51,14 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
                            size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode = GEMM_DEFAULT,
                            const void* rowtab = nullptr, int tab_rows = 0);
 // wd_ready: wd_ws already holds the flip-transposed weights (the trainer refreshes all layers in one launch per step)
+// rowtab_d: row table of the DGRAD geometry (see dgrad_geometry), optional
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
                         float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws = nullptr,
-                        size_t sk_floats = 0, int mode = GEMM_DEFAULT, bool wd_ready = false);
+                        size_t sk_floats = 0, int mode = GEMM_DEFAULT, bool wd_ready = false, const void* rowtab_d = nullptr,
+                        int rowtab_d_rows = 0);
+// geometry of the implicit GEMM that computes dX from dY for forward geometry g (stride 1: flipped SAME padding;
+// the strided 1x1 skip projection: a 1x1 GEMM over the output pixels, scattered by the epilogue)
+ConvGeom dgrad_geometry(const ConvGeom& g);
 
 // cached device allocations (net.hip): get may return stale contents, free never blocks on other streams
 void* pool_alloc(size_t bytes);
@@ -80,8 +85,10 @@ struct Op {
     int relu = 0, need_dgrad = 1, in_is_relu = 0, dgrad_accumulate = 0, dropout_layer = -1;
     float in_mask_scale = 1.f;
     int gemm_mode = GEMM_FP32;   // arithmetic of this layer's three GEMMs
-    void* rowtab = nullptr;    // conv: row table of the layer at the train batch (weight-gradient gather)
+    void* rowtab = nullptr;    // conv: row table of the layer (forward tile prologue and weight-gradient gather), max(batch, eval_batch) samples
     int rowtab_rows = 0;
+    void* rowtab_d = nullptr;  // conv: row table of the layer's dgrad geometry (dY as input, flipped padding), train batch
+    int rowtab_d_rows = 0;
     int64_t w_off = 0, b_off = 0, wd_off = -1;   // wd_off: this layer's slice of the flip-transposed copy (dgrad operand)
     int tensor_index = 0;   // canonical index of the kernel tensor (RNG init stream)
     // bn
@@ -133,7 +140,8 @@ class Net : public GemmHook {
     void backward(const float* X, const int32_t* idx, int64_t row0, int B, const StepState* st = nullptr);
     void step_body(const float* X, const int32_t* y, const int32_t* idx, int64_t row0, int B, const StepState* st);
     ConvGeom geom_of(const Op& op, int B) const;
-    void run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e, int* stats_blocks = nullptr);
+    void run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e, int* stats_blocks = nullptr,
+                  const void* rowtab = nullptr, int tab_rows = 0);
     float* dalloc(size_t floats);
 
     int32_t gene_[6];

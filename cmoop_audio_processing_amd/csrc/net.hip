@@ -350,10 +350,17 @@ void Net::build_plan() {
         }
         if (op.kind == OP_CONV) {   // (dense layers need no workspace: dense.hip)
             const ConvGeom g = geom_of(op, cfg_.batch);
-            if (op.KS * op.KS <= 32) {   // row table of the layer (geometry only): built once, serves every train batch size
-                op.rowtab_rows = rowtab_rows(g);
+            if (op.KS * op.KS <= 32) {   // row tables of the layer (geometry only): built once, serve every smaller batch
+                const ConvGeom gmax = geom_of(op, Bmax_);
+                op.rowtab_rows = rowtab_rows(gmax);
                 op.rowtab = dalloc((size_t)op.rowtab_rows * 2);
-                launch_build_rowtab(g, op.rowtab, stream_);
+                launch_build_rowtab(gmax, op.rowtab, stream_);
+                if (op.need_dgrad && ilog2_exact(op.Cout) >= 4) {
+                    const ConvGeom gd = dgrad_geometry(g);
+                    op.rowtab_d_rows = rowtab_rows(gd);
+                    op.rowtab_d = dalloc((size_t)op.rowtab_d_rows * 2);
+                    launch_build_rowtab(gd, op.rowtab_d, stream_);
+                }
             }
             // the slice count is NOT monotone in the batch rows (a smaller M can flip the K-tile width and the
             // co-resident workgroup count, so a partial last batch may ask for MORE slices than the full one):
@@ -502,7 +509,7 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
 // layer's input in the epilogue; accumulate adds into dX (second consumer of a tensor).
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
                         float mask_scale, int accumulate, hipStream_t s, GemmHook* hook, float* sk_ws, size_t sk_floats, int mode,
-                        bool wd_ready) {
+                        bool wd_ready, const void* rowtab_d, int rowtab_d_rows) {
     const int N = g.Cout;
     if (ilog2_exact(N) < 4) {   // output layer: K_dgrad = classes (10/11/35) -- tiny VALU kernel
         CMOOP_REQUIRE(g.KH == 1 && g.H == 1 && g.W == 1 && !accumulate, "non power-of-two C_out only supported for dense layers");
@@ -510,15 +517,10 @@ void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGe
         return;
     }
     if (!wd_ready) launch_flip_transpose(W, wd_ws, N, g.KH, g.KW, g.Cin, s);
-    ConvGeom gd;
+    const ConvGeom gd = dgrad_geometry(g);
     GemmEpilogue e;
-    gd.B = g.B; gd.H = g.OH; gd.W = g.OW; gd.Cin = N; gd.Cout = g.Cin; gd.stride = 1;
-    if (g.stride == 1) {
-        gd.OH = g.H; gd.OW = g.W; gd.KH = g.KH; gd.KW = g.KW;
-        gd.pad_t = g.KH - 1 - g.pad_t; gd.pad_l = g.KW - 1 - g.pad_l;
-    } else {
+    if (g.stride != 1) {
         CMOOP_REQUIRE(g.KH == 1 && g.KW == 1 && accumulate, "strided conv dgrad: only the 1x1 skip projection (accumulating)");
-        gd.OH = g.OH; gd.OW = g.OW; gd.KH = gd.KW = 1; gd.pad_t = gd.pad_l = 0;
         e.out_stride = g.stride; e.OHf = g.H; e.OWf = g.W;
     }
     e.mode = mode;
@@ -526,13 +528,26 @@ void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGe
     e.mask = mask;
     e.mask_scale = mask_scale;
     const GemmTiming* tm = hook ? hook->begin(0, 2.0 * gd.M() * (double)gd.Cout * gd.K()) : nullptr;
-    const int code = launch_igemm_fwd(dY, wd_ws, dX, gd, e, s, tm, sk_ws, sk_floats);
+    const int code = launch_igemm_fwd(dY, wd_ws, dX, gd, e, s, tm, sk_ws, sk_floats, nullptr, rowtab_d, rowtab_d_rows);
     if (hook) hook->end(code);
 }
 
-void Net::run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e, int* stats_blocks) {
+ConvGeom dgrad_geometry(const ConvGeom& g) {
+    ConvGeom gd;
+    gd.B = g.B; gd.H = g.OH; gd.W = g.OW; gd.Cin = g.Cout; gd.Cout = g.Cin; gd.stride = 1;
+    if (g.stride == 1) {
+        gd.OH = g.H; gd.OW = g.W; gd.KH = g.KH; gd.KW = g.KW;
+        gd.pad_t = g.KH - 1 - g.pad_t; gd.pad_l = g.KW - 1 - g.pad_l;
+    } else {
+        gd.OH = g.OH; gd.OW = g.OW; gd.KH = gd.KW = 1; gd.pad_t = gd.pad_l = 0;
+    }
+    return gd;
+}
+
+void Net::run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e, int* stats_blocks,
+                   const void* rowtab, int tab_rows) {
     const GemmTiming* tm = begin(cls, 2.0 * g.M() * (double)g.Cout * g.K());
-    end(launch_igemm_fwd(X, Wt, Y, g, e, stream_, tm, splitk_ws_, splitk_ws_floats_, stats_blocks));
+    end(launch_igemm_fwd(X, Wt, Y, g, e, stream_, tm, splitk_ws_, splitk_ws_floats_, stats_blocks, rowtab, tab_rows));
 }
 
 void Net::drain_profile() {
@@ -584,7 +599,7 @@ void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool 
             fused_stats_blocks_ = 0;
             if (train && op.feeds_bn) e.stats = red_ws_;    // BatchNorm batch statistics in the conv epilogue
             run_gemm(0, acts_[op.in].data, params_ + op.w_off, acts_[op.out].data, geom_of(op, B), e,
-                     e.stats ? &fused_stats_blocks_ : nullptr);
+                     e.stats ? &fused_stats_blocks_ : nullptr, op.rowtab, op.rowtab_rows);
             break;
         }
         case OP_DENSE: {
@@ -669,7 +684,7 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B, cons
             if (op.need_dgrad)
                 conv_backward_data(dY, params_ + op.w_off, ia.grad, g, wd_ws_ + op.wd_off, op.in_is_relu ? ia.data : nullptr,
                                    op.in_mask_scale, op.dgrad_accumulate, stream_, this, splitk_ws_, splitk_ws_floats_, op.gemm_mode,
-                                   true);
+                                   true, op.rowtab_d, op.rowtab_d_rows);
             break;
         }
         case OP_BN: {
