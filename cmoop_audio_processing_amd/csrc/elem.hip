@@ -720,6 +720,27 @@ void launch_gap_fwd(const float* X, float* Y, int B, int HW, int C, hipStream_t 
     CMOOP_HIP(hipGetLastError());
 }
 
+// seeded glorot-uniform initial weights / constant fill (Net::build_plan)
+__global__ __launch_bounds__(256) void glorot_init_kernel(float* __restrict__ w, int64_t n, uint32_t prefix, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int u24 = (int)(fmix32(prefix ^ (uint32_t)i) >> 8);
+        w[i] = (float)(2 * u24 - 16777216) * scale;
+    }
+}
+void launch_glorot_init(float* w, int64_t n, uint32_t prefix, float scale, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(glorot_init_kernel, dim3(ew_grid(n)), dim3(256), 0, s, w, n, prefix, scale);
+    CMOOP_HIP(hipGetLastError());
+}
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ w, float v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) w[i] = v;
+}
+void launch_fill(float* w, float v, int64_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, s, w, v, n);
+    CMOOP_HIP(hipGetLastError());
+}
+
 __global__ void step_advance_kernel(StepState* st, int batch) {
     st->row0 += batch;
     st->step += 1;

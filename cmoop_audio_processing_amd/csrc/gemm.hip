@@ -165,6 +165,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     constexpr bool DMA = MODE == GEMM_FP32_DMA;
     static_assert(!DMA || (BK == 32 && BM % 32 == 0 && BN % 32 == 0), "LDS-DMA image: 32-deep chunks, whole 8-row wave stripes");
     constexpr bool PIPE = false;   // software-pipelined main loop (see below): measured, no gain (it halves the global-load landing time)
+    // (Measured, NOT enabled: four chunks of global loads in flight for the 16-column tiles of the 16-filter layers -- 8 MFMAs
+    // per wave and chunk against a ~2 us global round trip.  The four register sets cost 146 VGPRs = 2 workgroups per CU instead
+    // of 5, and 16->16 k3 @101x40 forward fell from 42.9 to 31.9 TFLOP/s: occupancy hides that latency better than depth.)
+    constexpr bool DEEP4 = false;
     constexpr bool DIST2 = !PLANES && BM <= 64;   // two-chunk-deep global prefetch (two register sets); on 128-row tiles it costs the second workgroup per CU (measured 104 vs 124 TFLOP/s)
     constexpr int NP = MODE == GEMM_BF16X3 ? 3 : 1;
     constexpr int WN = 4 / WM;
@@ -257,7 +261,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     // two register sets: the loads of chunk c+2 are issued before chunk c is computed and are
     // written to LDS only after chunk c+1's compute, so a global-load round trip has two MFMA
     // phases to land (the 64-row tiles of the deep layers have only ~1k MFMA cycles per phase)
-    f32x4 ra0[APASS], rb0[BPASS], ra1[DIST2 ? APASS : 1], rb1[DIST2 ? BPASS : 1];
+    f32x4 ra0[APASS], rb0[BPASS], ra1[(DIST2 || DEEP4) ? APASS : 1], rb1[(DIST2 || DEEP4) ? BPASS : 1];
+    f32x4 ra2[DEEP4 ? APASS : 1], rb2[DEEP4 ? BPASS : 1], ra3[DEEP4 ? APASS : 1], rb3[DEEP4 ? BPASS : 1];
     // ---- fast operand loader (a K chunk lies inside ONE filter tap: Cin % BK == 0) -----------------------------------
     // Every non-MFMA vector instruction of a wave takes issue cycles from the matrix pipe it shares with its SIMD
     // partner (measured: the un-tuned loader's ~90 VALU per chunk cost 12-15 % of the kernel), so the per-chunk
@@ -469,6 +474,38 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             __syncthreads();
             if (c + 1 < nchunks) load_chunk(c + 1, ra0, rb0);
             compute(0);
+            __syncthreads();
+        }
+    } else if constexpr (DEEP4) {
+        // distance-4 prefetch: set (i mod 4) holds chunk i until it is stored to LDS image (i & 1) one iteration before use
+        const int n = nchunks - cbeg;
+        load_chunk(cbeg, ra0, rb0);
+        if (n > 1) load_chunk(cbeg + 1, ra1, rb1);
+        if (n > 2) load_chunk(cbeg + 2, ra2, rb2);
+        if (n > 3) load_chunk(cbeg + 3, ra3, rb3);
+        store_chunk(0, ra0, rb0);
+        __syncthreads();
+        for (int i = 0; i < n; i += 4) {
+            const int c = cbeg + i;
+            // chunk i (LDS 0): set 0 is free -> chunk i+4; set 1 (chunk i+1) goes to LDS 1 after the compute
+            if (i + 4 < n) load_chunk(c + 4, ra0, rb0);
+            compute(0);
+            if (i + 1 < n) store_chunk(1, ra1, rb1);
+            __syncthreads();
+            if (i + 1 >= n) break;
+            if (i + 5 < n) load_chunk(c + 5, ra1, rb1);
+            compute(1);
+            if (i + 2 < n) store_chunk(0, ra2, rb2);
+            __syncthreads();
+            if (i + 2 >= n) break;
+            if (i + 6 < n) load_chunk(c + 6, ra2, rb2);
+            compute(0);
+            if (i + 3 < n) store_chunk(1, ra3, rb3);
+            __syncthreads();
+            if (i + 3 >= n) break;
+            if (i + 7 < n) load_chunk(c + 7, ra3, rb3);
+            compute(1);
+            if (i + 4 < n) store_chunk(0, ra0, rb0);
             __syncthreads();
         }
     } else if constexpr (DIST2) {

@@ -96,6 +96,9 @@ struct StepState {
     unsigned iter;         // optimizer.iterations BEFORE this step's update (alpha_table[iter] is its step size)
 };
 void launch_step_advance(StepState* st, int batch, hipStream_t s);
+// w[i] = (float)(2 * (fmix32(prefix ^ i) >> 8) - 2^24) * scale: the seeded glorot-uniform twin of oracle/rng.py; constant fill
+void launch_glorot_init(float* w, int64_t n, uint32_t prefix, float scale, hipStream_t s);
+void launch_fill(float* w, float v, int64_t n, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Dense layers of the MLP head (dense.hip): M = batch rows, K = C_in (multiple of 16), N = units (any).
