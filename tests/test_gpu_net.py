@@ -479,6 +479,43 @@ def test_population_schema_determinism_and_problem_shim():
     assert np.allclose(out["G"][:, 1], out["F"][:, 1] - 2.5)
 
 
+def test_pull_queue_entry_point_matches_the_plain_population_call():
+    """cmoop_eval_population_pull (the C ABI the cross-rank queue binds): the library's worker threads call back into
+    Python for candidate indices.  Draining a local longest-first queue through it must give bit-identical results to
+    cmoop_eval_population, train every candidate exactly once, and hand out the expensive candidates first; a callback
+    that raises ends the workers and re-raises in the caller."""
+    import itertools
+    import random
+    import threading
+    classes = 10
+    cfg = EvalConfig.preset("nsga_penalty", epochs=2, batch=32, eval_batch=64, seed=9, n_slots=3, early_stop=False)
+    Xtr, ytr, Xva, yva = make_split(96, 64, 21, 12, classes, 77)
+    rng = random.Random(4)
+    genes = [G.normalize_hparams(G.random_hparams(rng)) for _ in range(7)]
+    seeds = [cfg.seed + i for i in range(7)]
+    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+    plain = ev.evaluate_genes(genes, seeds)
+    costs = [G.fwd_flops_per_sample(g, 0, classes, 21, 12) for g in genes]
+    order = sorted(range(7), key=lambda i: (-costs[i], i))
+    ctr, lock, handed = itertools.count(), threading.Lock(), []
+
+    def pull():
+        with lock:
+            j = next(ctr)
+            if j < 7:
+                handed.append(order[j])
+        return order[j] if j < 7 else -1
+    got = ev.evaluate_genes_pull(genes, seeds, pull)
+    assert sorted(got) == list(range(7)) and handed == order
+    for i in range(7):
+        assert np.array_equal(got[i][:4], plain[i][:4]), (i, got[i], plain[i])      # acc, size, fpr, epochs: bit-identical
+
+    def bad_pull():
+        raise RuntimeError("queue broke")
+    with pytest.raises(RuntimeError, match="queue broke"):
+        ev.evaluate_genes_pull(genes, seeds, bad_pull)
+
+
 def test_bad_inputs_fail_loudly():
     from cmoop_audio_processing_amd import _lib
     cfg = EvalConfig(epochs=1)
