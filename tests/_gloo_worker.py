@@ -69,15 +69,18 @@ def main():
 
     dist.barrier()
     out_q = queued_map(local_pull, est, 3, "test/queue/1", device="cpu")
-    out_s, _ = run_static()
+    dist.barrier()
+    out_s, t_static = run_static()          # includes waiting for the slower rank at the all_gather: the static makespan
     assert np.array_equal(out_q, out_s) and out_q[:, 0].tolist() == list(range(41))        # bit-identical to the static path
     import torch
-    t = torch.tensor([busy["t"]], dtype=torch.float64)
-    ts = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    t = torch.tensor([busy["t"], t_static], dtype=torch.float64)
+    ts = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(ts, t)
-    tq = [float(x) for x in ts]
-    assert max(tq) <= 1.10 * min(tq) + 2 * unit, f"queue left the ranks unbalanced: {tq}"
-    assert max(tq) < 0.8 * 41 * unit, f"queue no better than a static split: {tq}"        # static worst rank ~ 40 units
+    tq = [float(x[0]) for x in ts]
+    static_makespan = max(float(x[1]) for x in ts)
+    # (sleep-based simulated time: a few units of absolute slack absorb scheduler jitter on a loaded CI host)
+    assert max(tq) <= 1.10 * min(tq) + 4 * unit, f"queue left the ranks unbalanced: {tq}"
+    assert max(tq) < 0.9 * static_makespan, f"queue no better than the static split: {tq} vs {static_makespan}"   # ~30.5 vs ~40 units
     # empty generation and fewer candidates than ranks through the queue
     assert queued_map(lambda pull: {}, [], 2, "test/queue/2", device="cpu").shape == (0, 2)
     one = queued_map(lambda pull: {i: [7.0] for i in iter(pull, -1)}, [1.0], 1, "test/queue/3", device="cpu")
