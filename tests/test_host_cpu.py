@@ -94,8 +94,12 @@ def test_sharded_map_without_process_group_is_local():
 
 def test_sharding_world_size_2_gloo():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:      # a free port: a fixed one can still be in TIME_WAIT
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", os.path.join(ROOT, "tests", "_gloo_worker.py")]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_gloo_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "GLOO_WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
