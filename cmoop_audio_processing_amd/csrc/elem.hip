@@ -849,27 +849,141 @@ void launch_softmax_ce(const float* Z, const int32_t* labels, const int32_t* idx
     CMOOP_HIP(hipGetLastError());
 }
 
+// Every operation of the update is a separately rounded IEEE single operation, in the order the reference's CPU path and
+// the oracle apply them (oracle/net.py train_step): no fused multiply-add.  Left to the compiler, the contraction of
+// m + (g - m) * c1 differed BETWEEN TWO KERNELS of this file (fused in one, mul + add in the other), an ulp apart --
+// enough to change the predictions of a BatchNorm + dropout candidate 100 steps later.
+__device__ __forceinline__ void adam_update(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, int64_t i,
+                                            float gi, float alpha, float c1, float c2, float eps) {
+#pragma clang fp contract(off)
+    float mi = m[i], vi = v[i];
+    const float dm = (gi - mi) * c1;
+    mi = mi + dm;
+    const float gg = gi * gi;
+    const float dv = (gg - vi) * c2;
+    vi = vi + dv;
+    m[i] = mi;
+    v[i] = vi;
+    const float num = mi * alpha;
+    const float den = sqrtf(vi) + eps;
+    w[i] = w[i] - num / den;
+}
+
 // Keras-form Adam: m += (g-m)(1-b1); v += (g^2-v)(1-b2); w -= m*alpha/(sqrt(v)+eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float alpha, float c1, float c2,
                                                    float eps, const StepState* __restrict__ st,
                                                    const float* __restrict__ alpha_table) {
     if (st) alpha = alpha_table[st->iter];
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i];
-        float mi = m[i], vi = v[i];
-        mi = mi + (gi - mi) * c1;
-        vi = vi + (gi * gi - vi) * c2;
-        m[i] = mi;
-        v[i] = vi;
-        w[i] = w[i] - (mi * alpha) / (sqrtf(vi) + eps);
-    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        adam_update(w, m, v, i, g[i], alpha, c1, c2, eps);
 }
 
 void launch_adam(float* w, const float* g, float* m, float* v, int64_t n, float alpha, float c1, float c2, float eps,
                  hipStream_t s, const StepState* st, const float* alpha_table) {
     if (n == 0) return;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, s, w, g, m, v, n, alpha, c1, c2, eps, st, alpha_table);
+    CMOOP_HIP(hipGetLastError());
+}
+
+// slab segment: 64 column groups of VEC floats x 4 slice lanes per workgroup; lane sl sums slices sl, sl+4, ... with four
+// independent accumulators (the order of reduce_slices_kernel, gemm.hip), lane 0 combines, stores g and updates w/m/v
+template <int VEC>
+__device__ __forceinline__ void adam_slab_block(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
+                                                float* __restrict__ v, const AdamSeg sg, int b, float (*red)[256],
+                                                float alpha, float c1, float c2, float eps) {
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = ((int64_t)b * 64 + e) * VEC;
+    float acc[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[u][j] = 0.f;
+    if (i < sg.n) {
+        int s = sl;
+        for (; s + 12 < sg.S; s += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* src = sg.slab + (size_t)(s + 4 * u) * sg.stride + i;
+                if constexpr (VEC == 4) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(src);
+                    acc[u][0] += q[0]; acc[u][1] += q[1]; acc[u][2] += q[2]; acc[u][3] += q[3];
+                } else {
+                    acc[u][0] += src[0];
+                }
+            }
+        }
+        for (; s < sg.S; s += 4) {
+            const float* src = sg.slab + (size_t)s * sg.stride + i;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[0][j] += src[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[sl][e * VEC + j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+    __syncthreads();
+    if (sl == 0 && i < sg.n) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float gi = ((red[0][e * VEC + j] + red[1][e * VEC + j]) + red[2][e * VEC + j]) + red[3][e * VEC + j];
+            g[sg.off + i + j] = gi;
+            adam_update(w, m, v, sg.off + i + j, gi, alpha, c1, c2, eps);
+        }
+    }
+}
+
+constexpr int ADAM_PLAIN_PER_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void adam_segments_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
+                                                            float* __restrict__ v, const AdamSegTable tab, float alpha, float c1,
+                                                            float c2, float eps, const StepState* __restrict__ st,
+                                                            const float* __restrict__ alpha_table) {
+    __shared__ float red[4][256];
+    if (st) alpha = alpha_table[st->iter];
+    int si = 0;
+    while (si + 1 < tab.count && (int)blockIdx.x >= tab.seg[si + 1].block0) ++si;
+    const AdamSeg sg = tab.seg[si];
+    const int b = (int)blockIdx.x - sg.block0;
+    if (sg.slab == nullptr) {
+        const int64_t base = (int64_t)b * ADAM_PLAIN_PER_BLOCK;
+#pragma unroll
+        for (int k = 0; k < ADAM_PLAIN_PER_BLOCK / 256; ++k) {
+            const int64_t i = base + k * 256 + threadIdx.x;
+            if (i < sg.n) adam_update(w, m, v, sg.off + i, g[sg.off + i], alpha, c1, c2, eps);
+        }
+        return;
+    }
+    const bool vec = (sg.n % 4 == 0) && (sg.stride % 4 == 0) && (sg.off % 4 == 0) &&
+                     (reinterpret_cast<uintptr_t>(sg.slab) % 16 == 0);
+    if (vec) adam_slab_block<4>(w, g, m, v, sg, b, red, alpha, c1, c2, eps);
+    else adam_slab_block<1>(w, g, m, v, sg, b, red, alpha, c1, c2, eps);
+}
+
+void adam_segments_finalize(AdamSegTable& tab) {
+    CMOOP_REQUIRE(tab.count >= 0 && tab.count <= ADAM_MAX_SEGS, "adam segment table overflow");
+    int64_t blocks = 0, pos = tab.count ? tab.seg[0].off : 0;
+    for (int i = 0; i < tab.count; ++i) {
+        AdamSeg& sg = tab.seg[i];
+        CMOOP_REQUIRE(sg.off == pos && sg.n > 0, "adam segments must tile the arena in order");
+        pos += sg.n;
+        sg.block0 = (int32_t)blocks;
+        if (sg.slab) {
+            const bool vec = (sg.n % 4 == 0) && (sg.stride % 4 == 0) && (sg.off % 4 == 0) &&
+                             (reinterpret_cast<uintptr_t>(sg.slab) % 16 == 0);
+            blocks += vec ? cdiv64(sg.n / 4, 64) : cdiv64(sg.n, 64);
+        } else {
+            blocks += cdiv64(sg.n, ADAM_PLAIN_PER_BLOCK);
+        }
+    }
+    CMOOP_REQUIRE(blocks < (int64_t)1 << 30, "adam grid too large");
+    tab.blocks = (int32_t)blocks;
+}
+
+void launch_adam_segments(float* w, float* g, float* m, float* v, const AdamSegTable& tab, float alpha, float c1, float c2,
+                          float eps, hipStream_t s, const StepState* st, const float* alpha_table) {
+    if (tab.blocks == 0) return;
+    hipLaunchKernelGGL(adam_segments_kernel, dim3((unsigned)tab.blocks), dim3(256), 0, s, w, g, m, v, tab, alpha, c1, c2, eps, st,
+                       alpha_table);
     CMOOP_HIP(hipGetLastError());
 }
 

@@ -186,6 +186,25 @@ void launch_softmax_ce(const float* Z, const int32_t* labels, const int32_t* idx
 // st != null: alpha = alpha_table[st->iter] (host-precomputed per iteration: the Keras step size in double, rounded once)
 void launch_adam(float* w, const float* g, float* m, float* v, int64_t n, float alpha, float c1, float c2,
                  float eps, hipStream_t s, const StepState* st = nullptr, const float* alpha_table = nullptr);
+// One optimiser launch for the whole parameter arena that ALSO finishes the weight gradients: the arena is cut into
+// segments; a plain segment reads its gradient from g[], a slab segment sums the S row-slice partials its weight-gradient
+// kernel left in `slab` (same fixed order as reduce_slices_kernel), stores the sum to g[] and applies Adam to it.
+struct AdamSeg {
+    int64_t off = 0, n = 0;        // arena range [off, off + n)
+    const float* slab = nullptr;   // null: plain segment
+    int64_t stride = 0;            // floats between consecutive slices
+    int32_t S = 0;                 // slices
+    int32_t block0 = 0;            // first workgroup of the segment
+};
+constexpr int ADAM_MAX_SEGS = 64;
+struct AdamSegTable {
+    int32_t count = 0, blocks = 0;
+    AdamSeg seg[ADAM_MAX_SEGS];
+};
+// fills block0 / blocks from off, n, slab of the first `count` entries (segments must tile the arena in order)
+void adam_segments_finalize(AdamSegTable& tab);
+void launch_adam_segments(float* w, float* g, float* m, float* v, const AdamSegTable& tab, float alpha, float c1, float c2,
+                          float eps, hipStream_t s, const StepState* st = nullptr, const float* alpha_table = nullptr);
 // device twin of epoch_permutation (net.h): out[rank of key_i] = i; n <= EPOCH_PERMUTATION_DEVICE_MAX (O(n^2) rank sort)
 constexpr int64_t EPOCH_PERMUTATION_DEVICE_MAX = 262144;
 void launch_epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out, hipStream_t s);

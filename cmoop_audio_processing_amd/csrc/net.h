@@ -49,7 +49,9 @@ struct GemmHook {   // brackets every MFMA GEMM launch (HIP-event sampling)
 // wgrad_ws holds wgrad_ws_floats floats; the slice count is clamped to what fits (never written past)
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
                            size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode = GEMM_DEFAULT,
-                           const void* rowtab = nullptr, int tab_rows = 0);
+                           const void* rowtab = nullptr, int tab_rows = 0, AdamSeg* defer = nullptr);
+// defer != null (requires dB == dW + Cout*K): the slice sum is left to the optimiser launch -- *defer receives the slab
+// pointer / stride / slice count (slab stays null when one slice wrote dW, dB in place)
 // wd_ready: wd_ws already holds the flip-transposed weights (the trainer refreshes all layers in one launch per step)
 // rowtab_d: row table of the DGRAD geometry (see dgrad_geometry), optional
 void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGeom& g, float* wd_ws, const float* mask,
@@ -90,6 +92,8 @@ struct Op {
     void* rowtab_d = nullptr;  // conv: row table of the layer's dgrad geometry (dY as input, flipped padding), train batch
     int rowtab_d_rows = 0;
     int64_t w_off = 0, b_off = 0, wd_off = -1;   // wd_off: this layer's slice of the flip-transposed copy (dgrad operand)
+    int64_t slab_off = -1;     // conv / first conv: this layer's weight-gradient slabs in the candidate's slab arena
+    size_t slab_floats = 0;    // (kept until the optimiser launch sums them), sized for the worst train batch
     int tensor_index = 0;   // canonical index of the kernel tensor (RNG init stream)
     // bn
     int64_t gamma_off = 0, beta_off = 0, mm_off = 0, mv_off = 0;
@@ -163,6 +167,7 @@ class Net : public GemmHook {
     FlipEntry* flip_table_ = nullptr;   // device table of the conv layers whose dgrad needs flip-transposed weights
     int flip_layers_ = 0;
     int64_t flip_max_elems_ = 0;
+    std::vector<AdamSeg> slab_segs_;    // this step's unreduced weight-gradient slabs (backward fills, the optimiser launch consumes)
     size_t wgrad_ws_floats_ = 0, wd_ws_floats_ = 0, red_ws_floats_ = 0, splitk_ws_floats_ = 0;
     double* acc_train_ = nullptr;   // [2]: loss sum, correct (int64 bits)
     double* acc_eval_ = nullptr;

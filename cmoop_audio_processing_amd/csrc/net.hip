@@ -363,10 +363,13 @@ void Net::build_plan() {
             // the slice count is NOT monotone in the batch rows (a smaller M can flip the K-tile width and the
             // co-resident workgroup count, so a partial last batch may ask for MORE slices than the full one):
             // size the slab workspace for the worst train batch 1..cfg.batch
+            // Each layer owns its slabs: they live until the optimiser launch at the end of the step sums them.
             for (int b = 1; b <= cfg_.batch; ++b) {
                 const ConvGeom gb = geom_of(op, b);
-                wgrad_ws_floats_ = std::max(wgrad_ws_floats_, (size_t)wgrad_slices(gb) * gb.Cout * (gb.K() + 1));
+                op.slab_floats = std::max(op.slab_floats, (size_t)wgrad_slices(gb) * gb.Cout * (gb.K() + 1));
             }
+            op.slab_off = (int64_t)wgrad_ws_floats_;
+            wgrad_ws_floats_ += (op.slab_floats + 3) / 4 * 4;
             if (op.need_dgrad) { op.wd_off = (int64_t)wd_ws_floats_; wd_ws_floats_ += (size_t)g.Cout * g.K(); }
             // split-K slabs: forward (train and inference batch) and dgrad (input-shaped output)
             splitk_ws_floats_ = std::max(splitk_ws_floats_, igemm_splitk_workspace(g));
@@ -382,7 +385,9 @@ void Net::build_plan() {
         }
         if (op.kind == OP_CONV1) {
             const size_t per = (size_t)op.Cout * (op.KS * op.KS + 1);
-            wgrad_ws_floats_ = std::max(wgrad_ws_floats_, per * conv1_wgrad_blocks(cfg_.batch, T_, F_));
+            for (int b = 1; b <= cfg_.batch; ++b) op.slab_floats = std::max(op.slab_floats, per * conv1_wgrad_blocks(b, T_, F_));
+            op.slab_off = (int64_t)wgrad_ws_floats_;
+            wgrad_ws_floats_ += (op.slab_floats + 3) / 4 * 4;
             red_ws_floats_ = std::max(red_ws_floats_, (size_t)colreduce_blocks((int64_t)Bmax_ * T_ * F_, op.Cout) * 2 * op.Cout + 2 * op.Cout);
         }
         if (op.kind == OP_BN) {
@@ -476,7 +481,8 @@ void Net::end(int code) {
 
 // dW[N][K] and db[N] of a conv / dense layer: MFMA split over row slices, then a fixed-order slice sum
 void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB, const ConvGeom& g, float* wgrad_ws,
-                           size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode, const void* rowtab, int tab_rows) {
+                           size_t wgrad_ws_floats, hipStream_t s, GemmHook* hook, int mode, const void* rowtab, int tab_rows,
+                           AdamSeg* defer) {
     const int M = g.M(), N = g.Cout, K = g.K();
     int S = wgrad_slices(g);
     // never write past the slab workspace: fewer slices is always correct (each slice is a row range)
@@ -492,6 +498,14 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
     const GemmTiming* tm = hook ? hook->begin(1, 2.0 * M * (double)N * K) : nullptr;
     const int code = launch_igemm_wgrad(X, dY, Pk, g, S, s, tm, Pbias, in_place ? NK : stride, mode, rowtab, tab_rows);
     if (hook) hook->end(code);
+    if (defer) {
+        CMOOP_REQUIRE(dB == dW + NK, "deferred slice sum needs the bias gradient directly after the kernel gradient");
+        defer->n = (int64_t)stride;
+        defer->slab = in_place ? nullptr : wgrad_ws;
+        defer->stride = (int64_t)stride;
+        defer->S = S;
+        return;
+    }
     if (!in_place) {
         if (dB == dW + NK) {
             launch_reduce_slices(wgrad_ws, dW, S, (int64_t)stride, s, (int64_t)stride);
@@ -656,6 +670,7 @@ void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool 
 }
 
 void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B, const StepState* st) {
+    slab_segs_.clear();
     // dgrad operands: flip-transposed copies of every conv kernel, one launch for the whole net
     launch_flip_transpose_all(params_, wd_ws_, flip_table_, flip_layers_, flip_max_elems_, stream_);
     for (int oi = (int)ops_.size() - 1; oi >= 0; --oi) {
@@ -677,8 +692,11 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B, cons
             // (measured, not adopted: wgrad on a low-priority side stream forked per layer and joined before Adam -- off the
             // dgrad critical path -- ran 35 % SLOWER, 65 vs 100 TFLOP/s whole-job: the cross-stream event waits cost more
             // than the overlap wins)
-            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_, wgrad_ws_floats_, stream_, this, op.gemm_mode,
-                                  op.rowtab, op.rowtab_rows);
+            AdamSeg sg;
+            sg.off = op.w_off;
+            conv_backward_weights(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, g, wgrad_ws_ + op.slab_off, op.slab_floats, stream_,
+                                  this, op.gemm_mode, op.rowtab, op.rowtab_rows, &sg);
+            if (sg.slab) slab_segs_.push_back(sg);
             if (op.need_dgrad)
                 conv_backward_data(dY, params_ + op.w_off, ia.grad, g, wd_ws_ + op.wd_off, op.in_is_relu ? ia.data : nullptr,
                                    op.in_mask_scale, op.dgrad_accumulate, stream_, this, splitk_ws_, splitk_ws_floats_, op.gemm_mode,
@@ -718,9 +736,15 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B, cons
             break;
         }
         case OP_CONV1: {
-            launch_conv1_wgrad(X, idx, row0, acts_[op.out].grad, wgrad_ws_, B, T_, F_, op.Cout, op.KS, stream_, st);
-            launch_reduce_slices(wgrad_ws_, grads_ + op.w_off, conv1_wgrad_blocks(B, T_, F_),
-                                 (int64_t)op.Cout * (op.KS * op.KS + 1), stream_);
+            launch_conv1_wgrad(X, idx, row0, acts_[op.out].grad, wgrad_ws_ + op.slab_off, B, T_, F_, op.Cout, op.KS, stream_, st);
+            AdamSeg sg;
+            sg.off = op.w_off;
+            sg.n = sg.stride = (int64_t)op.Cout * (op.KS * op.KS + 1);
+            sg.slab = wgrad_ws_ + op.slab_off;
+            sg.S = conv1_wgrad_blocks(B, T_, F_);
+            CMOOP_REQUIRE((size_t)sg.S * sg.n <= op.slab_floats && op.b_off == op.w_off + (int64_t)op.Cout * op.KS * op.KS,
+                          "first-layer slab region");
+            slab_segs_.push_back(sg);
             break;
         }
         }
@@ -736,8 +760,33 @@ void Net::step_body(const float* X, const int32_t* y, const int32_t* idx, int64_
     const double t = (double)(iterations_ + 1);
     const double b1 = cfg_.beta1, b2 = cfg_.beta2;
     const float alpha = (float)(cfg_.lr * std::sqrt(1.0 - std::pow(b2, t)) / (1.0 - std::pow(b1, t)));
-    launch_adam(params_, grads_, adam_m_, adam_v_, n_params_, alpha, (float)(1.0 - b1), (float)(1.0 - b2),
-                (float)cfg_.adam_eps, stream_, st, alpha_tab_);
+    // ONE launch finishes the weight gradients (fixed-order sum of every layer's row-slice slabs) and applies Adam to the
+    // whole arena: the per-layer reduce_slices launches of round 1 are gone from the step
+    std::sort(slab_segs_.begin(), slab_segs_.end(), [](const AdamSeg& a, const AdamSeg& b) { return a.off < b.off; });
+    AdamSegTable tab;
+    int64_t pos = 0;
+    auto push = [&](const AdamSeg& sg) {
+        CMOOP_REQUIRE(tab.count < ADAM_MAX_SEGS, "too many optimiser segments");
+        tab.seg[tab.count++] = sg;
+    };
+    for (const AdamSeg& sg : slab_segs_) {
+        CMOOP_REQUIRE(sg.off >= pos && sg.off + sg.n <= n_params_, "slab segment outside the arena");
+        if (sg.off > pos) { AdamSeg pl; pl.off = pos; pl.n = sg.off - pos; push(pl); }
+        push(sg);
+        pos = sg.off + sg.n;
+    }
+    if (pos < n_params_) { AdamSeg pl; pl.off = pos; pl.n = n_params_ - pos; push(pl); }
+    const bool unfused = getenv("CMOOP_ADAM_UNFUSED") != nullptr;   // A/B knob (read per step: tests flip it): round-1 launch sequence
+    if (unfused) {
+        for (const AdamSeg& sg : slab_segs_) launch_reduce_slices(sg.slab, grads_ + sg.off, sg.S, sg.n, stream_, sg.stride);
+        launch_adam(params_, grads_, adam_m_, adam_v_, n_params_, alpha, (float)(1.0 - b1), (float)(1.0 - b2),
+                    (float)cfg_.adam_eps, stream_, st, alpha_tab_);
+        if (st) launch_step_advance(st_dev_, B, stream_);
+        return;
+    }
+    adam_segments_finalize(tab);
+    launch_adam_segments(params_, grads_, adam_m_, adam_v_, tab, alpha, (float)(1.0 - b1), (float)(1.0 - b2),
+                         (float)cfg_.adam_eps, stream_, st, alpha_tab_);
     if (st) launch_step_advance(st_dev_, B, stream_);
 }
 

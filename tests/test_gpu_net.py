@@ -317,6 +317,31 @@ def test_wgrad_workspace_partial_batches_advice_r1(B):
         l_g, a_g, _ = net.evaluate(Xd, yd)
         assert abs(l_g - l_o) < 1e-3 * max(1.0, abs(l_o)), (l_g, l_o)
 
+def test_optimiser_launch_sums_the_weight_gradient_slabs_bit_exactly(monkeypatch):
+    """r2: the per-layer reduce_slices launches are folded into ONE optimiser launch (slab segments summed in the same fixed
+    order, then Adam).  Four steps (full, partial, full, full batch -- the slice counts change with B) of a BatchNorm +
+    dropout candidate must leave bit-identical parameters and gradients under the round-1 launch sequence
+    (CMOOP_ADAM_UNFUSED, read per step).  Adam's arithmetic is pinned (no FMA contraction): left to the compiler the two
+    kernels rounded m differently and this comparison failed by an ulp at step 4."""
+    gene, classes, seed = (16, 3, 1, 2, 2, 1), 11, 11
+    cfg = EvalConfig.preset("sa_nsga_penalty", classes=classes, batch=32, eval_batch=64, seed=seed, n_slots=1)
+    X, y = make_data(128, 41, 20, classes, 5)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    got = {}
+    for mode in ("fused", "unfused"):
+        if mode == "unfused":
+            monkeypatch.setenv("CMOOP_ADAM_UNFUSED", "1")
+        else:
+            monkeypatch.delenv("CMOOP_ADAM_UNFUSED", raising=False)
+        with NetSession(gene, cfg, 41, 20, seed) as net:
+            for step, b in enumerate((32, 19, 32, 32)):
+                net.train_step(Xd, yd, None, row0=32 * step, B=b)
+            got[mode] = (np.array(net.get_params()), np.array(net.get_grads()))
+    monkeypatch.delenv("CMOOP_ADAM_UNFUSED", raising=False)
+    for a, b in zip(got["fused"], got["unfused"]):
+        assert np.isfinite(a).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 
 def test_population_40_at_baseline_feature_size_config1():
     """BASELINE configs[1] at full population and feature size: the 40 genes of random.Random(0) (the bench's
