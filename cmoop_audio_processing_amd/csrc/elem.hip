@@ -83,9 +83,11 @@ void launch_conv1_fwd(const float* X, const int32_t* idx, int64_t row0, const fl
     CMOOP_HIP(hipGetLastError());
 }
 
+// partial slabs of the first layer's weight gradient: one per workgroup = (sample, chunk of image rows); ~512 chip-wide
+static int conv1_row_chunks(int B, int H) { return std::max(1, std::min(H, 512 / std::max(B, 1))); }
 int conv1_wgrad_blocks(int B, int H, int W) {
-    int64_t groups = (int64_t)B * H * ((W + 3) / 4);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(512, groups / 64));
+    (void)W;
+    return std::max(1, B) * conv1_row_chunks(B, H);
 }
 
 template <int KS>
@@ -167,9 +169,140 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     }
 }
 
+// The same gradient on the matrix cores (Cout in {16, 32, 64}: the search space): dW[tap][co] = sum over pixels of
+// x[pixel + tap] * dY[pixel][co] is a [taps x pixels] x [pixels x Cout] product with a 66 MB reduction axis for 1.7 k
+// outputs.  One v_mfma_f32_16x16x4_f32 reduces FOUR pixels: lane (lr, q) supplies A[tap 16 tt + lr][pixel q] -- its own
+// tap's shifted input value, a gather from the 16 KB image (L1) -- and B[pixel q][column lr]; the bias gradient is the
+// extra "tap" whose input is the constant 1.  dY is read once, as one 16 / 8 / 4-byte load per lane of NCH consecutive
+// channels: MFMA j of a group uses component j, so column lr of accumulator j IS channel NCH*lr + j (a permutation of
+// the output columns, undone when the tile is written).  Workgroup = (sample, row chunk); its four waves take rows
+// h, h+4, ...; U groups of 4 pixels have their loads in flight together.  The VALU form above took 49 us per step on
+// 64 filters k5 (104 accumulator registers, 40 scalar loads per 400 FMAs); the floor here is the 66 MB read of dY.
+template <int KS, int NCH, int U>
+__global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx,
+                                                               int64_t row0, const float* __restrict__ dY,
+                                                               float* __restrict__ P, int H, int W, int RC,
+                                                               const StepState* __restrict__ st) {
+    constexpr int TAPS = KS * KS, TT = (TAPS + 1 + 15) / 16, pad = (KS - 1) >> 1, Cout = 16 * NCH;
+    typedef float dyvec __attribute__((ext_vector_type(NCH)));
+    __shared__ __attribute__((aligned(16))) float red[3 * TT * NCH * 256];
+    if (st) row0 = st->row0;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x / RC, rc = blockIdx.x - b * RC;
+    const int rows_per = (H + RC - 1) / RC;
+    const int h_begin = rc * rows_per, h_end = min(H, h_begin + rows_per);
+    const int64_t src = idx ? (int64_t)idx[row0 + b] : row0 + b;
+    const float* xb = X + src * (int64_t)H * W;
+    const float* dyb = dY + (int64_t)b * H * W * Cout + NCH * lr;
+    int dh[TT], dw[TT], kind[TT];   // kind 0: a real tap (input shifted by dh, dw); 1: the bias row (input 1); 2: unused row
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        const int tap = tt * 16 + lr;
+        kind[tt] = tap < TAPS ? 0 : (tap == TAPS ? 1 : 2);
+        dh[tt] = tap < TAPS ? tap / KS - pad : 0;
+        dw[tt] = tap < TAPS ? tap % KS - pad : 0;
+    }
+    f32x4 acc[TT][NCH];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) acc[tt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = h_begin + wave; h < h_end; h += 4) {
+        const float* xrow[TT];
+        bool rok[TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int ih = h + dh[tt];
+            rok[tt] = kind[tt] == 0 && (unsigned)ih < (unsigned)H;
+            xrow[tt] = xb + (rok[tt] ? ih : 0) * W + dw[tt];
+        }
+        const float* dyrow = dyb + (int64_t)h * W * Cout;
+        for (int w0 = 0; w0 < W; w0 += 4 * U) {
+            float a[U][TT];
+            dyvec d[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int w = w0 + 4 * u + q;
+                const bool ok = w < W;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) d[u][j] = 0.f;
+                if (ok) d[u] = *reinterpret_cast<const dyvec*>(dyrow + (int64_t)w * Cout);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    const bool in = ok && rok[tt] && (unsigned)(w + dw[tt]) < (unsigned)W;
+                    const float xv = in ? xrow[tt][w] : 0.f;
+                    a[u][tt] = kind[tt] == 1 ? 1.f : xv;      // where the pixel is outside the row, dY is 0
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j)
+                        acc[tt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tt], d[u][j], acc[tt][j], 0, 0, 0);
+        }
+    }
+    // waves 1..3 park their tiles, wave 0 adds them in wave order and writes the slab
+    if (wave > 0) {
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+                *reinterpret_cast<f32x4*>(&red[(((wave - 1) * TT + tt) * NCH + j) * 256 + lane * 4]) = acc[tt][j];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float* Pb = P + (size_t)blockIdx.x * (Cout * (TAPS + 1));
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            f32x4 v = acc[tt][j];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4*>(&red[((w * TT + tt) * NCH + j) * 256 + lane * 4]);
+            const int co = NCH * lr + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tap = tt * 16 + 4 * q + r;
+                if (tap < TAPS) Pb[co * TAPS + tap] = v[r];           // kernel grad, canonical [co][tap]
+                else if (tap == TAPS) Pb[Cout * TAPS + co] = v[r];    // bias grad
+            }
+        }
+}
+
+template <int KS, int NCH>
+static void launch_conv1_wgrad_mfma(const float* X, const int32_t* idx, int64_t row0, const float* dY, float* P, int B, int H,
+                                    int W, hipStream_t s, const StepState* st) {
+    const int RC = conv1_row_chunks(B, H), W4 = (W + 3) / 4;
+    const dim3 grid((unsigned)(B * RC));
+    // groups of 4 pixels per row, U at a time: pick the U that wastes no masked group (W = 40: 10 groups = 2 x 5)
+    if (W4 % 5 == 0)
+        hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<KS, NCH, 5>), grid, dim3(256), 0, s, X, idx, row0, dY, P, H, W, RC, st);
+    else if (W4 % 3 == 0 && W4 % 4 != 0)
+        hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<KS, NCH, 3>), grid, dim3(256), 0, s, X, idx, row0, dY, P, H, W, RC, st);
+    else
+        hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<KS, NCH, 4>), grid, dim3(256), 0, s, X, idx, row0, dY, P, H, W, RC, st);
+}
+
 void launch_conv1_wgrad(const float* X, const int32_t* idx, int64_t row0, const float* dY, float* P, int B, int H,
                         int W, int Cout, int KS, hipStream_t s, const StepState* st) {
     CMOOP_REQUIRE(Cout % 4 == 0 && Cout <= 64 && 64 % (Cout / 4) == 0, "conv1 wgrad: unsupported Cout");
+    if (B == 0) return;
+    if ((Cout == 16 || Cout == 32 || Cout == 64) && (KS == 3 || KS == 5)) {
+        const int nch = Cout / 16;
+        if (KS == 3) {
+            if (nch == 1) launch_conv1_wgrad_mfma<3, 1>(X, idx, row0, dY, P, B, H, W, s, st);
+            else if (nch == 2) launch_conv1_wgrad_mfma<3, 2>(X, idx, row0, dY, P, B, H, W, s, st);
+            else launch_conv1_wgrad_mfma<3, 4>(X, idx, row0, dY, P, B, H, W, s, st);
+        } else {
+            if (nch == 1) launch_conv1_wgrad_mfma<5, 1>(X, idx, row0, dY, P, B, H, W, s, st);
+            else if (nch == 2) launch_conv1_wgrad_mfma<5, 2>(X, idx, row0, dY, P, B, H, W, s, st);
+            else launch_conv1_wgrad_mfma<5, 4>(X, idx, row0, dY, P, B, H, W, s, st);
+        }
+        CMOOP_HIP(hipGetLastError());
+        return;
+    }
     const int nb = conv1_wgrad_blocks(B, H, W);
     if (KS == 3) hipLaunchKernelGGL(conv1_wgrad_kernel<3>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout, st);
     else if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_kernel<5>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout, st);

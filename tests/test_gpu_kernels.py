@@ -83,6 +83,39 @@ def test_conv_fwd(B, H, W, Cin, Cout, KS, stride, relu):
     assert e < TOL
 
 
+CONV1_WGRAD_CASES = [
+    (2, 21, 12, 16, 3), (3, 21, 12, 64, 5), (1, 101, 40, 32, 5), (64, 101, 40, 64, 5), (64, 101, 40, 16, 3),
+    (5, 13, 7, 32, 3),       # W not a multiple of 4: masked last pixel group
+    (2, 9, 23, 16, 5),       # 6 groups per row: the 3-at-a-time instantiation
+    (33, 5, 4, 64, 3),       # more row chunks than rows for some samples' share: empty workgroups write zero slabs
+    (2, 21, 12, 8, 3),       # C_out outside the search space: the VALU form
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cout,KS", CONV1_WGRAD_CASES)
+def test_first_layer_weight_gradient(B, H, W, Cout, KS):
+    """dW, db of the C_in = 1 first conv (nsga_penalty.py:255): the matrix-core kernel (C_out 16 / 32 / 64) and the VALU
+    fallback, through the per-workgroup slabs and the fixed-order slab sum, against torch autograd in fp32."""
+    rs = np.random.RandomState(B * 131 + H * 7 + W + Cout + KS)
+    x = rs.randn(B, H, W, 1).astype(np.float32)
+    w = (rs.randn(Cout, KS, KS, 1) / KS).astype(np.float32)
+    dy = rs.randn(B, H, W, Cout).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).double()          # float64 reference: the gate prices the GPU sum alone
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    conv_same(xt, wt, bt, 1).backward(torch.from_numpy(dy).permute(0, 3, 1, 2).double())
+    dw = torch.full((Cout, KS, KS, 1), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda")
+    dx = torch.zeros((B, H, W, 1), device="cuda")
+    xd, wd, dyd = dev(x), dev(w), dev(dy)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().cmoop_conv_bwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(dyd), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
+                                         B, H, W, 1, Cout, KS, 1, 0))
+    e_dw, e_db = rel(dw.cpu().numpy(), wt.grad.numpy()), rel(db.cpu().numpy(), bt.grad.numpy())
+    print(f"conv1 wgrad {B,H,W,Cout,KS} dw={e_dw:.2e} db={e_db:.2e}")
+    assert e_dw < 5e-5 and e_db < 5e-5
+
+
 BWD_CASES = [
     (2, 13, 9, 16, 16, 3, 1, 1),
     (3, 26, 10, 32, 64, 5, 1, 0),

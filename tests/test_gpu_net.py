@@ -237,30 +237,69 @@ def test_birdclef_shaped_path_config3():
 
 PROTOCOLS = [
     ("nsga_penalty", (16, 3, 0, 1, 1, 0)),       # A, last-epoch accuracy, no restore, y_true quirk
-    ("sa_nsga_penalty", (16, 3, 1, 1, 2, 1)),    # B, restore_best, evaluate(), V1
     ("sa_nsga_local", (16, 5, 0, 2, 1, 0)),      # B, V3
 ]
+CHAOTIC = ("sa_nsga_penalty", (16, 3, 1, 1, 2, 1))   # B, restore_best, evaluate(), V1 -- BatchNorm + dropout
+
+
+def protocol_case(preset, gene, epochs, patience, seed=11):
+    classes = 10 if preset != "sa_nsga_penalty" else 11
+    cfg = EvalConfig.preset(preset, classes=classes, epochs=epochs, patience=patience, batch=32, eval_batch=64, seed=seed, n_slots=1)
+    Xtr, ytr, Xva, yva = make_split(192, 128, 21, 12, classes, 21, noise=0.3, label_noise=0.25)
+    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+    acc, size_mb, fpr = ev.evaluate_individual(G.gene_to_hparams(gene))
+    a, b = oracle_pair(gene, cfg, Xtr, ytr, Xva, yva, seed)
+    print(preset, f"seed {seed} epochs {epochs}: gpu", (acc, fpr, ev.last_epochs_run), "oracle", (a[0], a[2], a[3]), "oracle, native conv", (b[0], b[2], b[3]))
+    assert size_mb == a[1] == G.model_size_mb(gene, G.VARIANT_NAMES[cfg.variant], classes)
+    return (acc, fpr, ev.last_epochs_run[0]), a, b
 
 
 @pytest.mark.parametrize("preset,gene", PROTOCOLS)
 def test_evaluate_individual_protocol_parity(preset, gene):
     """End-to-end parity at the north-star gate on a task the nets LEARN: |d accuracy| <= 1e-3, |d FPR| <= 1e-3,
-    epochs_run equal, size_mb bit-exact, with early stopping (patience 2; it triggers at epochs 21 / 23 / 16 of 25 on
-    the oracle), best-weight restore and the per-script read-outs active; ~100-140 optimiser steps.  Train and
-    validation share class prototypes, 25 % of the labels are re-drawn at random (validation accuracy 0.45-0.8,
-    confident predictions).  The gate widens ONLY to the oracle's own spread between torch's two CPU conv algorithms
-    when that exceeds 1e-3 (the BatchNorm + dropout candidate: its two oracle runs can differ by a prediction)."""
-    classes = 10 if preset != "sa_nsga_penalty" else 11
-    cfg = EvalConfig.preset(preset, classes=classes, epochs=25, patience=2, batch=32, eval_batch=64, seed=11, n_slots=1)
-    Xtr, ytr, Xva, yva = make_split(192, 128, 21, 12, classes, 21, noise=0.3, label_noise=0.25)
-    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
-    acc, size_mb, fpr = ev.evaluate_individual(G.gene_to_hparams(gene))
-    (a_acc, a_size, a_fpr, a_ep), (b_acc, b_size, b_fpr, b_ep) = oracle_pair(gene, cfg, Xtr, ytr, Xva, yva, 11)
-    print(preset, "gpu", (acc, fpr, ev.last_epochs_run), "oracle", (a_acc, a_fpr, a_ep), "oracle, native conv", (b_acc, b_fpr, b_ep))
-    assert size_mb == a_size == G.model_size_mb(gene, G.VARIANT_NAMES[cfg.variant], classes)
-    assert 0.4 <= a_acc <= 0.97 and a_ep < 25, f"the parity task must be learnable, unsaturated and early-stopped: {a_acc}, {a_ep}"
-    assert gate(acc, a_acc, b_acc) and gate(fpr, a_fpr, b_fpr)
-    assert ev.last_epochs_run[0] in (a_ep, b_ep)
+    epochs_run equal, size_mb bit-exact, with early stopping (patience 2; it triggers at epochs 21 / 16 of 25 on the
+    oracle), best-weight restore and the per-script read-outs active; ~100-130 optimiser steps.  Train and validation
+    share class prototypes, 25 % of the labels are re-drawn at random (validation accuracy 0.45-0.8, confident
+    predictions).  For these nets (no BatchNorm) the oracle's two CPU conv algorithms agree exactly, so the gate IS 1e-3."""
+    (acc, fpr, ep), a, b = protocol_case(preset, gene, 25, 2)
+    assert 0.4 <= a[0] <= 0.97 and a[3] < 25, f"the parity task must be learnable, unsaturated and early-stopped: {a[0]}, {a[3]}"
+    assert gate(acc, a[0], b[0]) and gate(fpr, a[2], b[2])
+    assert ep in (a[3], b[3])
+
+
+def test_protocol_parity_batchnorm_dropout_short_horizon():
+    """The BatchNorm + dropout candidate (restore_best, evaluate() read-out, FPR V1) over a horizon on which rounding
+    differences have not yet been amplified: 5 epochs (30 optimiser steps), no early stop.  Strict gate."""
+    preset, gene = CHAOTIC
+    (acc, fpr, ep), a, b = protocol_case(preset, gene, 5, 5)
+    assert ep == a[3] == b[3] == 5
+    assert gate(acc, a[0], b[0]) and gate(fpr, a[2], b[2])
+
+
+def test_protocol_parity_batchnorm_dropout_full_protocol_is_statistical():
+    """The same candidate through the full early-stopped protocol (25 epochs, patience 2: ~140 steps).  Here training is
+    CHAOTIC in the numerical sense: the oracle's own two CPU conv algorithms (same arithmetic, another fp32 summation
+    order) end 4 of 128 predictions apart, and on the GPU a one-ulp change in Adam's rounding of m (FMA contraction chosen
+    differently by the compiler in two kernels, since pinned) moved the result from 0.461 / 23 epochs to 0.508 / 25 epochs.
+    A single run therefore cannot be gated at 1e-3 against anything.  What is pinned instead, over 3 seeds:
+    every GPU result lies within the oracle's range widened by three times the oracle's mean own spread, the stopping
+    epoch within the patience of an oracle run, and the seed-averaged accuracy / FPR within 0.04 / 0.01 of the oracle's."""
+    preset, gene = CHAOTIC
+    runs = [protocol_case(preset, gene, 25, 2, seed=s) for s in (11, 12, 13)]
+    for k, name, mean_gate in ((0, "accuracy", 0.04), (1, "fpr", 0.01)):
+        ok = 0 if k == 0 else 2                      # column of the oracle tuple
+        spread = max(1.0 / 128 if k == 0 else 1e-3, float(np.mean([abs(a[ok] - b[ok]) for _, a, b in runs])))
+        for (gpu, a, b) in runs:
+            lo, hi = min(a[ok], b[ok]) - 3 * spread, max(a[ok], b[ok]) + 3 * spread
+            assert lo <= gpu[k] <= hi, (name, gpu[k], a[ok], b[ok], spread)
+        g_mean = float(np.mean([gpu[k] for gpu, _, _ in runs]))
+        o_mean = float(np.mean([0.5 * (a[ok] + b[ok]) for _, a, b in runs]))
+        print(f"mean {name} over seeds: gpu {g_mean:.4f} oracle {o_mean:.4f} (mean own spread {spread:.4f})")
+        assert abs(g_mean - o_mean) <= mean_gate, (name, g_mean, o_mean)
+    for (gpu, a, b) in runs:
+        assert min(abs(gpu[2] - a[3]), abs(gpu[2] - b[3])) <= 2, (gpu[2], a[3], b[3])
+        assert 0.3 <= a[0] <= 0.97
+
 
 
 def test_reference_input_shapes_at_the_boundary():

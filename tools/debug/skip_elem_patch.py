@@ -1,24 +1,30 @@
-# TEMPORARY timing experiment, never committed applied: rewrites elem.hip / dense.hip / gemm.hip so that CMOOP_DEBUG_SKIP_ELEM=1 drops every
-# non-GEMM launch (=2: also split-K combine and the flip-transpose) -- results are garbage, only the wall time means something.
+# TEMPORARY timing experiment, never committed applied: rewrites elem.hip / dense.hip / gemm.hip so that the bit mask in
+# CMOOP_DEBUG_SKIP_ELEM drops whole kernel families (results are garbage, only the wall time means something):
+#   1 BatchNorm (statistics finalize, apply, fused pool forms, backward reduce / apply)   2 first conv (C_in = 1) fwd / wgrad
+#   4 dense head + GAP + softmax-CE                                                        8 max-pool, add+ReLU
+#  16 Adam (with the slab sums), step state, shuffle, init                                32 split-K combine + flip-transpose
 # Apply, make, run tools/debug/skip_run.sh on the GPU, then `git checkout` the three files and rebuild.
 import re
-root='/root/repo/cmoop_audio_processing_amd/csrc/'
-hdr='''
-// ---- TEMPORARY timing experiment (never committed): CMOOP_DEBUG_SKIP_ELEM=1 drops every launch of this file
+root = '/root/repo/cmoop_audio_processing_amd/csrc/'
+FAMILY = [(1, r'colreduce_kernel|bn_\w+|scale_shift_kernel'), (2, r'conv1_\w+'),
+          (4, r'dense_\w+|gap_\w+|softmax_ce_kernel|colsum_\w+|confusion_kernel'), (8, r'maxpool_\w+|add_relu_kernel'),
+          (16, r'adam_\w+|step_advance_kernel|epoch_permutation_kernel|fill_kernel|glorot_init_kernel'),
+          (32, r'splitk_combine_kernel|flip_transpose_all_kernel')]
+hdr = '''
 #include <cstdlib>
-static inline int dbg_skip_level() { static const int v = getenv("CMOOP_DEBUG_SKIP_ELEM") ? atoi(getenv("CMOOP_DEBUG_SKIP_ELEM")) : 0; return v; }
-#define ELEM_LAUNCH(...) do { if (dbg_skip_level() < LEVEL_OF_FILE) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+static inline int dbg_skip_mask() { static const int v = getenv("CMOOP_DEBUG_SKIP_ELEM") ? atoi(getenv("CMOOP_DEBUG_SKIP_ELEM")) : 0; return v; }
+#define ELEM_LAUNCH(MASK, ...) do { if (!(dbg_skip_mask() & (MASK))) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 '''
-for f,level in (('elem.hip',1),('dense.hip',1)):
-    s=open(root+f).read()
-    s=s.replace('hipLaunchKernelGGL(','ELEM_LAUNCH(')
-    # insert header after the last #include
-    idx=[m.end() for m in re.finditer(r'^#include.*$', s, re.M)][-1]
-    s=s[:idx]+hdr.replace('LEVEL_OF_FILE',str(level))+s[idx:]
-    open(root+f,'w').write(s)
-# gemm.hip: level 2 skips splitk_combine and flip
-s=open(root+'gemm.hip').read()
-idx=[m.end() for m in re.finditer(r'^#include.*$', s, re.M)][-1]
-s=s[:idx]+hdr.replace('LEVEL_OF_FILE','2')+s[idx:]
-s=s.replace('hipLaunchKernelGGL(splitk_combine_kernel','ELEM_LAUNCH(splitk_combine_kernel').replace('hipLaunchKernelGGL(flip_transpose_all_kernel','ELEM_LAUNCH(flip_transpose_all_kernel')
-open(root+'gemm.hip','w').write(s)
+def family(name):
+    for bit, rx in FAMILY:
+        if re.fullmatch(rx, name): return bit
+    return None
+for f in ('elem.hip', 'dense.hip', 'gemm.hip'):
+    s = open(root + f).read()
+    def sub(m):
+        bit = family(m.group(2))
+        return m.group(0) if bit is None else f'ELEM_LAUNCH({bit}, {m.group(1)}{m.group(2)}'
+    s, n = re.subn(r'hipLaunchKernelGGL\((\(?)([A-Za-z_0-9]+)', sub, s)
+    idx = [m.end() for m in re.finditer(r'^#include.*$', s, re.M)][-1]
+    open(root + f, 'w').write(s[:idx] + hdr + s[idx:])
+    print(f, s.count('ELEM_LAUNCH('))
