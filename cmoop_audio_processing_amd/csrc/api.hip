@@ -178,6 +178,15 @@ int cmoop_logmel(const float* wav_dev, int64_t n_clips, int32_t n_samples, float
     });
 }
 
+int cmoop_mfcc(const float* logmel_dev, int64_t rows, int32_t n_mels, int32_t n_mfcc, float* out_dev) {
+    return guard([&] {
+        CMOOP_REQUIRE(rows >= 0 && logmel_dev != out_dev, "mfcc: out of place, rows >= 0");
+        hipStream_t s = lib_stream();
+        launch_mfcc(logmel_dev, out_dev, rows, n_mels, n_mfcc, s);
+        CMOOP_HIP(hipStreamSynchronize(s));
+    });
+}
+
 int cmoop_standardize_fit(const float* x_dev, int64_t rows, int32_t cols, double* mean_host, double* scale_host) {
     return guard([&] {
         CMOOP_REQUIRE(rows >= 1 && cols >= 4 && cols % 4 == 0, "standardize: cols must be a multiple of 4");

@@ -281,6 +281,43 @@ void launch_logmel(const float* wav, int64_t n_clips, int n_samples, float* out,
     CMOOP_HIP(hipGetLastError());
 }
 
+// MFCC option ("optional DCT-II ortho -> 40 MFCC"; the reference's own comment calls its features MFCCs,
+// sa_nsga_init.py:68): out[row][k] = s_k * sum_f x[row][f] * cos(pi (f + 1/2) k / n), s_0 = sqrt(1/n), s_k = sqrt(2/n)
+// -- scipy.fft.dct(type=2, norm="ortho") along the mel axis, first n_out coefficients.  HBM-bound (rows = clips x frames):
+// a workgroup stages 32 rows and the n x n basis (built in double, once per workgroup) in LDS, 8 threads per row.
+constexpr int MFCC_MAX = 64, MFCC_ROWS = 32;
+__global__ __launch_bounds__(256) void mfcc_kernel(const float* __restrict__ X, float* __restrict__ Y, int64_t rows, int n,
+                                                   int n_out) {
+    __shared__ float basis[MFCC_MAX * (MFCC_MAX + 1)];
+    __shared__ float xs[MFCC_ROWS * (MFCC_MAX + 1)];
+    const int t = threadIdx.x;
+    for (int i = t; i < n_out * n; i += 256) {
+        const int k = i / n, f = i - k * n;
+        const double sk = k == 0 ? sqrt(1.0 / n) : sqrt(2.0 / n);
+        basis[k * (MFCC_MAX + 1) + f] = (float)(sk * cos(M_PI * (f + 0.5) * k / n));
+    }
+    const int64_t row0 = (int64_t)blockIdx.x * MFCC_ROWS;
+    for (int i = t; i < MFCC_ROWS * n; i += 256) {
+        const int r = i / n, f = i - r * n;
+        xs[r * (MFCC_MAX + 1) + f] = row0 + r < rows ? X[(row0 + r) * n + f] : 0.f;
+    }
+    __syncthreads();
+    const int r = t >> 3;
+    if (row0 + r >= rows) return;
+    for (int k = t & 7; k < n_out; k += 8) {
+        float acc = 0.f;
+        for (int f = 0; f < n; ++f) acc = fmaf(xs[r * (MFCC_MAX + 1) + f], basis[k * (MFCC_MAX + 1) + f], acc);
+        Y[(row0 + r) * n_out + k] = acc;
+    }
+}
+
+void launch_mfcc(const float* X, float* Y, int64_t rows, int n_mels, int n_mfcc, hipStream_t s) {
+    CMOOP_REQUIRE(n_mels >= 1 && n_mels <= MFCC_MAX && n_mfcc >= 1 && n_mfcc <= n_mels, "mfcc: 1 <= n_mfcc <= n_mels <= 64");
+    if (rows == 0) return;
+    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)cdiv64(rows, MFCC_ROWS)), dim3(256), 0, s, X, Y, rows, n_mels, n_mfcc);
+    CMOOP_HIP(hipGetLastError());
+}
+
 // StandardScaler (nsga_penalty.py:103-141): mean / sqrt(biased var) per mel bin over N*T rows
 __global__ void colstats_f64_kernel(const float* __restrict__ P, int blocks, int64_t M, int C, double* __restrict__ mean,
                                     double* __restrict__ scale) {

@@ -1398,7 +1398,8 @@ int wgrad_slices(const ConvGeom& g) {
         }
         return 8 * best;
     }
-    int S = cdiv((int)(2048 * par_scale()), tiles);
+    static const int target_wgs = [] { const char* e = std::getenv("CMOOP_WGRAD_WGS"); const int v = e ? std::atoi(e) : 0; return v >= 256 && v <= 8192 ? v : 2048; }();
+    int S = cdiv((int)(target_wgs * par_scale()), tiles);
     // cap the slab traffic (S*N*K floats written and read back): at most ~16M floats, but keep >= 8 slices
     const int64_t nk = (int64_t)N * K;
     const int cap = (int)std::max<int64_t>(8, (16ll << 20) / std::max<int64_t>(nk, 1));

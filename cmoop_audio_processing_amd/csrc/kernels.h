@@ -222,6 +222,7 @@ struct FrontendTables;   // device-resident twiddles / window / sparse mel weigh
 FrontendTables* frontend_tables_create(const FrontendCfg& c);
 void frontend_tables_destroy(FrontendTables* t);
 void launch_logmel(const float* wav, int64_t n_clips, int n_samples, float* out, const FrontendTables* t, hipStream_t s);
+void launch_mfcc(const float* X, float* Y, int64_t rows, int n_mels, int n_mfcc, hipStream_t s);   // DCT-II ortho along the mel axis
 void launch_standardize(float* X, const double* mean, const double* scale, int64_t rows, int C, hipStream_t s);
 void colstats_finalize_f64(const float* P, int blocks, int64_t M, int C, double* mean, double* scale, hipStream_t s);
 

@@ -69,6 +69,11 @@ class EvalConfig:
     # counter on the c10d store; balances early-stopped runs whose epoch counts are unknown in advance);
     # "static" = LPT buckets by closed-form FLOPs.  Results are bit-identical either way (per-candidate seeds).
     schedule: str = "dynamic"
+    # result packing of compute_objectives_and_constraints: "all" = [-acc, size, fpr] (nsga_penalty.py:418-442); the
+    # bi-objective ablations keep the third quantity as a tracked key and drop its constraint from CV:
+    # "acc_fpr" (acc_fpr_nsga_1.py:283-310, 'size_metric'), "acc_size" (acc_size_nsga_1.py:283-311, 'fpr_metric'),
+    # "size_fpr" (size_fpr_nsga_1.py:283-310, 'acc_metric')
+    objectives: str = "all"
 
     @staticmethod
     def preset(script: str, **over) -> "EvalConfig":
@@ -90,6 +95,14 @@ class EvalConfig:
             # ablation_study/init_sa_nsga_local.py: topology B, vectorised V1 (:137-143)
             "init_sa_nsga_local": dict(variant="B", classes=10, restore_best=True, acc_readout="evaluate",
                                        fpr_variant="v1", min_accuracy=0.90, max_model_size=2.5, max_fpr=0.09),
+            # ablation_study/{acc_fpr,acc_size,size_fpr}_nsga_1.py: topology A, restore_best (:246), evaluate() (:249),
+            # FPR V1 on y.flatten() (:225-237), train-only scaler (:90-100), thresholds :148-149, two objectives
+            "acc_fpr_nsga_1": dict(variant="A", classes=10, restore_best=True, acc_readout="evaluate", fpr_variant="v1",
+                                   min_accuracy=0.90, max_model_size=2.5, max_fpr=0.09, objectives="acc_fpr"),
+            "acc_size_nsga_1": dict(variant="A", classes=10, restore_best=True, acc_readout="evaluate", fpr_variant="v1",
+                                    min_accuracy=0.90, max_model_size=2.5, max_fpr=0.09, objectives="acc_size"),
+            "size_fpr_nsga_1": dict(variant="A", classes=10, restore_best=True, acc_readout="evaluate", fpr_variant="v1",
+                                    min_accuracy=0.90, max_model_size=2.5, max_fpr=0.09, objectives="size_fpr"),
         }
         if script not in table:
             raise KeyError(f"unknown preset {script!r}; have {sorted(table)}")
@@ -359,15 +372,29 @@ class PopulationEvaluator:
         for ind, r in zip(population, res):
             acc, size_mb, fpr = float(r[0]), float(r[1]), float(r[2])
             self._print(r)
-            g1 = max(0.0, c.min_accuracy - acc)
-            g2 = max(0.0, size_mb - c.max_model_size)
-            g3 = max(0.0, fpr - c.max_fpr)
-            results.append({"hparams": ind, "objs": [-acc, size_mb, fpr], "CV": g1 + g2 + g3})
+            results.append(pack_result(ind, acc, size_mb, fpr, c))
         return results
 
     def _print(self, r):
         if self.config.verbose:
             print(f"  -> True Eval: Acc={r[0]:.4f}, Size={r[1]:.2f}MB, FPR={r[2]:.4f}")
+
+
+def pack_result(ind: Dict, acc: float, size_mb: float, fpr: float, c: EvalConfig) -> Dict:
+    """One entry of compute_objectives_and_constraints' result list, in the schema of the script ``c.objectives`` names
+    (holding a REFERENCE to the caller's hparams dict, as nsga_penalty.py:438 does)."""
+    g1 = max(0.0, c.min_accuracy - acc)
+    g2 = max(0.0, size_mb - c.max_model_size)
+    g3 = max(0.0, fpr - c.max_fpr)
+    if c.objectives == "all":
+        return {"hparams": ind, "objs": [-acc, size_mb, fpr], "CV": g1 + g2 + g3}
+    if c.objectives == "acc_fpr":
+        return {"hparams": ind, "objs": [-acc, fpr], "size_metric": size_mb, "CV": g1 + g3}
+    if c.objectives == "acc_size":
+        return {"hparams": ind, "objs": [-acc, size_mb], "fpr_metric": fpr, "CV": g1 + g2}
+    if c.objectives == "size_fpr":
+        return {"hparams": ind, "acc_metric": acc, "objs": [size_mb, fpr], "CV": g2 + g3}
+    raise ValueError(f"unknown objectives {c.objectives!r}")
 
 
 class AudioNASProblem:

@@ -31,6 +31,19 @@ def log_mel(wav):
     return out
 
 
+def mfcc(wav, n_mfcc: int = N_MELS):
+    """wav: CUDA float32 [N, L] -> CUDA float32 [N, 1 + L//160, n_mfcc]: DCT-II (ortho) of the log-mel frames."""
+    import torch
+    lm = log_mel(wav)
+    n, T = int(lm.shape[0]), int(lm.shape[1])
+    if not 1 <= n_mfcc <= N_MELS:
+        raise ValueError("1 <= n_mfcc <= 40")
+    out = torch.empty((n, T, n_mfcc), dtype=torch.float32, device=lm.device)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().cmoop_mfcc(_lib.ptr(lm), C.c_int64(n * T), C.c_int32(N_MELS), C.c_int32(n_mfcc), _lib.ptr(out)))
+    return out
+
+
 def standardize_fit(x):
     """StandardScaler.fit over x.reshape(-1, F): (mean, scale) float64 numpy arrays."""
     import torch

@@ -124,10 +124,28 @@ def feasible_pareto(pop_data: Sequence[Dict]) -> List[Dict]:
     return [feas[i] for i in fast_non_dominated_sort(feas, LAMBDA_FINAL)[0]]
 
 
+def accuracy_size_fpr(ind: Dict) -> Tuple[float, float, float]:
+    """(accuracy, size_mb, fpr) of a result entry in any of the four packings: three objectives
+    (nsga_penalty.py:438) or a bi-objective ablation with the third quantity under its tracked key
+    (acc_fpr_nsga_1.py:304-309 'size_metric', acc_size_nsga_1.py:306-310 'fpr_metric', size_fpr_nsga_1.py:304-309 'acc_metric')."""
+    o = ind["objs"]
+    if len(o) == 3:
+        return -o[0], o[1], o[2]
+    if "size_metric" in ind:
+        return -o[0], ind["size_metric"], o[1]
+    if "fpr_metric" in ind:
+        return -o[0], o[1], ind["fpr_metric"]
+    return ind["acc_metric"], o[0], o[1]
+
+
 def generation_records(gen: int, pop_data: Sequence[Dict]) -> List[Dict]:
-    """Rows with the reference's per-generation column schema (nsga_penalty.py:708-719)."""
-    return [{"Generation": gen, "Accuracy": -ind["objs"][0], "Size_MB": ind["objs"][1], "FPR": ind["objs"][2],
-             "CV": ind["CV"], **ind["hparams"]} for ind in pop_data]
+    """Rows with the reference's per-generation column schema (nsga_penalty.py:708-719; the ablations write the same
+    columns, reading the tracked quantity from its key: acc_size_nsga_1.py:476-483)."""
+    out = []
+    for ind in pop_data:
+        acc, size_mb, fpr = accuracy_size_fpr(ind)
+        out.append({"Generation": gen, "Accuracy": acc, "Size_MB": size_mb, "FPR": fpr, "CV": ind["CV"], **ind["hparams"]})
+    return out
 
 
 def nsga2(evaluate: Callable[[List[Dict]], List[Dict]], pop_size: int, max_gen: int, seed: int = 0,

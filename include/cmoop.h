@@ -117,6 +117,10 @@ int cmoop_calculate_fpr(const int32_t* y_true, const int32_t* y_pred, int64_t n,
  *      nsga_penalty.py:64-71) and prepare_dataset's StandardScaler (nsga_penalty.py:103-141) */
 int cmoop_logmel(const float* wav_dev /* [n_clips][n_samples] */, int64_t n_clips, int32_t n_samples,
                  float* out_dev /* [n_clips][1+n_samples/160][40] */);
+/* optional MFCC features: DCT-II, ortho-normalised, along the mel axis of log-mel rows; first n_mfcc coefficients.
+ * The reference ships no front end; its comment at ablation_study/sa_nsga_init.py:68 calls the stored features MFCCs. */
+int cmoop_mfcc(const float* logmel_dev /* [rows][n_mels] */, int64_t rows, int32_t n_mels, int32_t n_mfcc,
+               float* out_dev /* [rows][n_mfcc] */);
 int cmoop_standardize_fit(const float* x_dev, int64_t rows, int32_t cols, double* mean_host, double* scale_host);
 int cmoop_standardize_apply(float* x_dev, int64_t rows, int32_t cols, const double* mean_host, const double* scale_host);
 

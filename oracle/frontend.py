@@ -80,6 +80,12 @@ def log_mel(wav, sr=16000, n_fft=512, win_length=400, hop=160, n_mels=40, fmin=2
     return out
 
 
+def mfcc(wav, n_mfcc=40, **kw):
+    """DCT-II (orthonormal) of the log-mel frames along the mel axis, first n_mfcc coefficients (scipy.fft.dct)."""
+    from scipy.fft import dct
+    return dct(log_mel(wav, **kw), type=2, norm="ortho", axis=-1)[..., :n_mfcc]
+
+
 def scaler_fit(X):
     """StandardScaler.fit over rows of X.reshape(-1, F): (mean, scale) float64."""
     flat = np.asarray(X, dtype=np.float64).reshape(-1, X.shape[-1])

@@ -253,6 +253,29 @@ def test_frontend_logmel_and_standardize():
     assert np.abs(feats.cpu().numpy() - ofe.scaler_transform(out.cpu().numpy(), mean, scale)).max() < 1e-5
 
 
+def test_frontend_mfcc_option():
+    """MFCC option (DCT-II ortho of the log-mel frames) vs the oracle (scipy.fft.dct in float64).  The DCT kernel
+    alone, fed the GPU's own log-mel, is gated at 2e-5 of the largest coefficient; end to end the log-mel tolerance
+    (2e-4 absolute per bin) passes through an orthonormal transform: |err| <= 2e-4 * sqrt(40)."""
+    from scipy.fft import dct
+    from cmoop_audio_processing_amd import frontend as fe
+    from oracle import frontend as ofe
+    rs = np.random.RandomState(5)
+    n, L = 5, 16000
+    t = np.arange(L) / 16000.0
+    wav = np.stack([0.4 * np.sin(2 * np.pi * (150 + 410 * i) * t) + 0.2 * rs.randn(L) for i in range(n)]).astype(np.float32)
+    lm = fe.log_mel(dev(wav)).cpu().numpy()
+    for n_mfcc in (40, 13, 1):
+        out = fe.mfcc(dev(wav), n_mfcc).cpu().numpy()
+        assert out.shape == (n, 101, n_mfcc)
+        ref_kernel = dct(lm.astype(np.float64), type=2, norm="ortho", axis=-1)[..., :n_mfcc]
+        assert np.abs(out - ref_kernel).max() < 2e-5 * np.abs(ref_kernel).max()
+        assert np.abs(out - ofe.mfcc(wav, n_mfcc)).max() < 2e-4 * np.sqrt(40.0)
+    assert fe.mfcc(torch.zeros((0, 16000), device="cuda"), 13).shape == (0, 101, 13)
+    with pytest.raises(ValueError):
+        fe.mfcc(dev(wav), 41)
+
+
 def test_device_epoch_permutation_equals_the_host_and_oracle_twins():
     """The trainer's per-epoch shuffle is computed on the GPU (rank sort of the counter-RNG keys); it must be the
     permutation the host twin (C ABI) and the oracle (oracle/rng.py) produce -- bit-exact, all sizes incl. ragged

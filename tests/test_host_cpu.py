@@ -179,3 +179,40 @@ def test_wgrad_slice_count_is_not_monotone_in_the_batch_and_the_abi_reports_it()
             if spec["name"] in ("conv2",) or spec["name"].endswith("conv2"):
                 h, w = (h + 1) // 2, (w + 1) // 2
     assert 0 < worst < (1 << 26)
+
+
+def test_result_packing_matches_every_reference_script(golden_dir):
+    """compute_objectives_and_constraints' result entries -- three objectives (nsga_penalty.py:418-442,
+    sa_nsga_penalty.py:231-253) and the bi-objective ablations with their tracked keys (acc_fpr_nsga_1.py:283-310,
+    acc_size_nsga_1.py:283-311, size_fpr_nsga_1.py:283-310) -- against the outputs of the reference's own functions
+    (tests/golden/make_golden.py), bit for bit, including key order and the reference to the caller's dict; and the
+    per-generation CSV row read back from any packing."""
+    import json
+    from cmoop_audio_processing_amd.evaluator import EvalConfig, pack_result
+    from cmoop_audio_processing_amd.nsga import accuracy_size_fpr, generation_records
+    preset_of = {"nsga_penalty.py": "nsga_penalty", "sa_nsga_penalty.py": "sa_nsga_penalty",
+                 "ablation_study/acc_fpr_nsga_1.py": "acc_fpr_nsga_1", "ablation_study/acc_size_nsga_1.py": "acc_size_nsga_1",
+                 "ablation_study/size_fpr_nsga_1.py": "size_fpr_nsga_1"}
+    g = json.load(open(os.path.join(golden_dir, "objectives_golden.json")))
+    seen = set()
+    for case in g["cases"]:
+        cfg = EvalConfig.preset(preset_of[case["script"]])
+        t = case["thresholds"]
+        used = {"all": ("MIN_ACCURACY", "MAX_MODEL_SIZE", "MAX_FPR"), "acc_fpr": ("MIN_ACCURACY", "MAX_FPR"),
+                "acc_size": ("MIN_ACCURACY", "MAX_MODEL_SIZE"), "size_fpr": ("MAX_MODEL_SIZE", "MAX_FPR")}[cfg.objectives]
+        ours = {"MIN_ACCURACY": cfg.min_accuracy, "MAX_MODEL_SIZE": cfg.max_model_size, "MAX_FPR": cfg.max_fpr}
+        assert all(ours[k] == t[k] for k in used)
+        seen.add(cfg.objectives)
+        for r in case["records"]:
+            hp = {"filters": 16}
+            out = pack_result(hp, r["acc"], r["size_mb"], r["fpr"], cfg)
+            assert out["hparams"] is hp and out["objs"] == r["objs"] and out["CV"] == r["CV"]
+            for key in ("size_metric", "fpr_metric", "acc_metric"):
+                assert (key in out) == (key in r) and (key not in r or out[key] == r[key])
+            assert accuracy_size_fpr(out) == (r["acc"], r["size_mb"], r["fpr"])
+            row = generation_records(3, [out])[0]
+            assert (row["Generation"], row["Accuracy"], row["Size_MB"], row["FPR"], row["CV"], row["filters"]) == \
+                   (3, r["acc"], r["size_mb"], r["fpr"], r["CV"], 16)
+    assert seen == {"all", "acc_fpr", "acc_size", "size_fpr"}
+    with pytest.raises(ValueError):
+        pack_result({}, 0.9, 1.0, 0.1, EvalConfig(objectives="nope"))

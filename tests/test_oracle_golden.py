@@ -207,3 +207,19 @@ def test_fp32_oracle_trained_bn_net_depends_on_the_summation_order():
     assert abs(a[0] - b[0]) > 1e-3 or a[3] != b[3], (a, b)
     a, b = both((16, 5, 0, 2, 1, 0))        # no BatchNorm: self-consistent
     assert abs(a[0] - b[0]) <= 1e-3 and abs(a[2] - b[2]) <= 1e-3 and a[3] == b[3], (a, b)
+
+
+def test_oracle_mfcc_is_the_orthonormal_dct_of_log_mel():
+    """oracle/frontend.py mfcc (SURVEY 8d optional MFCC): explicit orthonormal DCT-II basis == scipy's, energy preserved
+    at 40 of 40 coefficients, truncation keeps the leading ones."""
+    from oracle import frontend as ofe
+    rs = np.random.RandomState(1)
+    wav = (0.3 * rs.randn(2, 4000)).astype(np.float32)
+    lm, full, part = ofe.log_mel(wav), ofe.mfcc(wav, 40), ofe.mfcc(wav, 13)
+    n = 40
+    k, f = np.arange(n)[:, None], np.arange(n)[None, :]
+    basis = np.sqrt(2.0 / n) * np.cos(np.pi * (f + 0.5) * k / n)
+    basis[0] = np.sqrt(1.0 / n)
+    assert np.abs(lm @ basis.T - full).max() < 1e-10
+    assert np.allclose((full ** 2).sum(-1), (lm ** 2).sum(-1), rtol=1e-12)
+    assert np.array_equal(part, full[..., :13])
