@@ -180,7 +180,7 @@ int cmoop_logmel(const float* wav_dev, int64_t n_clips, int32_t n_samples, float
 
 int cmoop_mfcc(const float* logmel_dev, int64_t rows, int32_t n_mels, int32_t n_mfcc, float* out_dev) {
     return guard([&] {
-        CMOOP_REQUIRE(rows >= 0 && logmel_dev != out_dev, "mfcc: out of place, rows >= 0");
+        CMOOP_REQUIRE(rows >= 0 && (rows == 0 || (logmel_dev && out_dev && logmel_dev != out_dev)), "mfcc: out of place, rows >= 0");
         hipStream_t s = lib_stream();
         launch_mfcc(logmel_dev, out_dev, rows, n_mels, n_mfcc, s);
         CMOOP_HIP(hipStreamSynchronize(s));
