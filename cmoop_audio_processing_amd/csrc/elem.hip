@@ -386,28 +386,38 @@ void launch_bn_bwd_reduce(const float* dY, const float* X, const float* mean, co
     CMOOP_HIP(hipGetLastError());
 }
 
-// Sum the per-block partials of one channel: 8 channels per 256-thread block, 32 lanes per
-// channel stride over the partial blocks, then lane 0 adds the 32 lane sums in order (fixed order
-// -> deterministic, chain length blocks/32 instead of blocks).
+// Per-channel totals of the [blocks][2][C] partials a reduction (or a conv epilogue) left: PS_CH channels per workgroup,
+// 64 lanes per channel, lane l sums partials l, l+64, ... into four independent double accumulators (eight loads in
+// flight: the 4 040 partials of a 101x40 layer are 16 rounds, not 126), then lane 0 adds the 64 lane sums in lane order.
+constexpr int PS_CH = 4;
 __device__ __forceinline__ bool partial_sums(const float* __restrict__ P, int blocks, int C, double* s1, double* s2,
                                              int* c_out) {
-    __shared__ double sh[2][8][32];
-    const int cl = threadIdx.x >> 5, lane = threadIdx.x & 31;
-    const int c = blockIdx.x * 8 + cl;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int blk = lane; blk < blocks; blk += 32) {
-            a += (double)P[(size_t)blk * 2 * C + c];
-            b += (double)P[(size_t)blk * 2 * C + C + c];
+    __shared__ double sh[2][PS_CH][64];
+    const int cl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * PS_CH + cl;
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c < C) {
+        int blk = lane;
+        for (; blk + 192 < blocks; blk += 256) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] += (double)P[(size_t)(blk + 64 * u) * 2 * C + c];
+                b[u] += (double)P[(size_t)(blk + 64 * u) * 2 * C + C + c];
+            }
         }
-    sh[0][cl][lane] = a;
-    sh[1][cl][lane] = b;
+        for (; blk < blocks; blk += 64) {
+            a[0] += (double)P[(size_t)blk * 2 * C + c];
+            b[0] += (double)P[(size_t)blk * 2 * C + C + c];
+        }
+    }
+    sh[0][cl][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+    sh[1][cl][lane] = (b[0] + b[1]) + (b[2] + b[3]);
     __syncthreads();
     *c_out = c;
     if (lane != 0 || c >= C) return false;
-    a = 0.0; b = 0.0;
-    for (int l = 0; l < 32; ++l) { a += sh[0][cl][l]; b += sh[1][cl][l]; }
-    *s1 = a; *s2 = b;
+    double x = 0.0, y = 0.0;
+    for (int l = 0; l < 64; ++l) { x += sh[0][cl][l]; y += sh[1][cl][l]; }
+    *s1 = x; *s2 = y;
     return true;
 }
 
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 void launch_bn_finalize(const float* P, int blocks, int64_t M, int C, const float* gamma, const float* beta,
                         float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale, float* shift,
                         float eps, float momentum, float omm, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, P, blocks, M, C, gamma, beta, moving_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, PS_CH)), dim3(256), 0, s, P, blocks, M, C, gamma, beta, moving_mean,
                        moving_var, mean, invstd, scale, shift, eps, momentum, omm);
     CMOOP_HIP(hipGetLastError());
 }
@@ -532,7 +542,7 @@ void launch_bn_bwd_apply(const float* dY, const float* X, const float* mean, con
                          int mask_x_pos, hipStream_t s) {
     // sums live right after the partials (caller reserves 2*C floats there)
     float* sums = const_cast<float*>(P) + (size_t)blocks * 2 * C;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, P, blocks, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, PS_CH)), dim3(256), 0, s, P, blocks, C, sums, dgamma, dbeta);
     CMOOP_HIP(hipGetLastError());
     const int64_t n4 = M * C / 4;
     if (n4 == 0) return;
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 }
 
 void launch_colsum_finalize(const float* P, int blocks, int C, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, P, blocks, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, PS_CH)), dim3(256), 0, s, P, blocks, C, out);
     CMOOP_HIP(hipGetLastError());
 }
 
@@ -796,7 +806,7 @@ void launch_bn_pool_bwd_apply(const float* g_pooled, const uint8_t* arg, const f
                               int H, int W, int C, int mask_x_pos, hipStream_t s) {
     const int64_t M = (int64_t)B * H * W;
     float* sums = const_cast<float*>(P) + (size_t)blocks * 2 * C;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, P, blocks, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, PS_CH)), dim3(256), 0, s, P, blocks, C, sums, dgamma, dbeta);
     CMOOP_HIP(hipGetLastError());
     const int64_t n4 = M * C / 4;
     if (n4 == 0) return;
@@ -1020,23 +1030,23 @@ void launch_adam(float* w, const float* g, float* m, float* v, int64_t n, float 
 }
 
 // slab segment: 64 column groups of VEC floats x 4 slice lanes per workgroup; lane sl sums slices sl, sl+4, ... with four
-// independent accumulators (the order of reduce_slices_kernel, gemm.hip), lane 0 combines, stores g and updates w/m/v
+// independent accumulators of eight (the order of reduce_slices_kernel, gemm.hip), lane 0 combines, stores g and updates w/m/v
 template <int VEC>
 __device__ __forceinline__ void adam_slab_block(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
                                                 float* __restrict__ v, const AdamSeg sg, int b, float (*red)[256],
                                                 float alpha, float c1, float c2, float eps) {
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t i = ((int64_t)b * 64 + e) * VEC;
-    float acc[4][VEC];
+    float acc[8][VEC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[u][j] = 0.f;
     if (i < sg.n) {
         int s = sl;
-        for (; s + 12 < sg.S; s += 16) {
+        for (; s + 28 < sg.S; s += 32) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const float* src = sg.slab + (size_t)(s + 4 * u) * sg.stride + i;
                 if constexpr (VEC == 4) {
                     const f32x4 q = *reinterpret_cast<const f32x4*>(src);
@@ -1053,7 +1063,8 @@ __device__ __forceinline__ void adam_slab_block(float* __restrict__ w, float* __
         }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) red[sl][e * VEC + j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+    for (int j = 0; j < VEC; ++j)
+        red[sl][e * VEC + j] = ((acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j])) + ((acc[4][j] + acc[5][j]) + (acc[6][j] + acc[7][j]));
     __syncthreads();
     if (sl == 0 && i < sg.n) {
 #pragma unroll

@@ -1486,23 +1486,23 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
 }
 
 // out[i] = sum_s P[s][i], fixed summation order.  Vector form: each thread owns one float4 column group,
-// 4 slice lanes x 4 independent accumulators keep 16 loads of 16 B in flight per thread.
+// 4 slice lanes x 8 independent accumulators keep 8 loads of 16 B in flight per thread (512 first-layer slabs: 16 rounds).
 template <int VEC>
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ P, float* __restrict__ out, int S,
                                                             int64_t n, int64_t stride) {
     __shared__ float red[4][64 * VEC];
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t i = ((int64_t)blockIdx.x * 64 + e) * VEC;
-    float acc[4][VEC];
+    float acc[8][VEC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[u][j] = 0.f;
     if (i < n) {
         int s = sl;
-        for (; s + 12 < S; s += 16) {
+        for (; s + 28 < S; s += 32) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const float* src = P + (size_t)(s + 4 * u) * stride + i;
                 if constexpr (VEC == 4) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(src);
@@ -1519,7 +1519,8 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restr
         }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) red[sl][e * VEC + j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+    for (int j = 0; j < VEC; ++j)
+        red[sl][e * VEC + j] = ((acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j])) + ((acc[4][j] + acc[5][j]) + (acc[6][j] + acc[7][j]));
     __syncthreads();
     if (sl == 0 && i < n) {
 #pragma unroll
