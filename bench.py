@@ -220,6 +220,7 @@ class StubEvaluator:
         from cmoop_audio_processing_amd import evaluator as E
         self.E, self.config, self.variant, self.classes, self.T, self.F = E, cfg, variant, classes, T, F
         self.ms_per_gflop = ms_per_gflop
+        self.slots = int(getattr(cfg, "n_slots", 8))
         self.evals_done, self._gen = 0, 0
         self.last_rank_of = []
         E._queue_serial[0] += 1
@@ -237,9 +238,12 @@ class StubEvaluator:
             time.sleep(costs[i] * self.ms_per_gflop * 1e-3)
             return [0.5, G.model_size_mb(gl[i], self.variant, self.classes), 0.05, rank]
 
-        def local(pull):
-            return {i: one(i) for i in iter(pull, -1)}
-        res = self.E.queued_map(local, costs, 4, f"{self._prefix}/{self._gen}")
+        def local(pull, workers):
+            import concurrent.futures as cf
+            with cf.ThreadPoolExecutor(max_workers=workers) as ex:      # as many pullers as the real evaluator's worker threads
+                parts = list(ex.map(lambda _: {i: one(i) for i in iter(pull, -1)}, range(workers)))
+            return {i: r for part in parts for i, r in part.items()}
+        res = self.E.queued_map(local, costs, 4, f"{self._prefix}/{self._gen}", slots=self.slots)
         self.evals_done += len(gl)
         self.last_rank_of = [int(r) for r in res[:, 3]]
         return [{"hparams": hp, "objs": [-r[0], r[1], r[2]], "CV": 0.0} for hp, r in zip(population, res)]

@@ -28,7 +28,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass, replace
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -189,9 +189,35 @@ def _default_store():
     return c10d._get_default_store()
 
 
-def queued_map(local_pull_fn: Callable[[Callable[[], int]], Dict[int, Sequence[float]]], costs: Sequence[float], width: int,
-               key: str, device: str = "cpu") -> np.ndarray:
+def queue_plan(costs: Sequence[float], world: int, slots: int) -> Tuple[List[int], int, List[List[int]]]:
+    """(cost-sorted order, workers per rank W, head lists per rank) of the cross-rank queue.
+
+    W = min(slots, ceil(n / world)): no rank STARTS more than its fair share of the generation at once.  Without that
+    bound 8 ranks x 8 worker threads drain a 40-candidate queue in one burst of fetch-adds and who trains what is a race
+    (the rank that hosts the store answers itself fastest and would collect the largest candidates).  The first
+    world * W positions of the longest-first order -- what the workers start with -- are therefore dealt out
+    deterministically, longest first to the least-loaded rank that still has a free worker (capacity-constrained LPT on
+    the closed-form cost); only what is left after that goes through the shared counter.  n <= world * W: the whole
+    generation is that static deal.  Same inputs on every rank -> same plan, no communication."""
+    n = len(costs)
+    order = sorted(range(n), key=lambda i: (-costs[i], i))      # longest first, ties by index (same on every rank)
+    W = max(1, min(int(slots), -(-n // max(world, 1)))) if n else 1
+    heads: List[List[int]] = [[] for _ in range(world)]
+    loads = [0.0] * world
+    for i in order[:min(n, world * W)]:
+        r = min((q for q in range(world) if len(heads[q]) < W), key=lambda q: (loads[q], q))
+        heads[r].append(i)
+        loads[r] += costs[i]
+    return order, W, heads
+
+
+def queued_map(local_pull_fn: Callable[..., Dict[int, Sequence[float]]], costs: Sequence[float], width: int,
+               key: str, device: str = "cpu", slots: Optional[int] = None) -> np.ndarray:
     """Evaluate items 0..n-1 across the ranks through ONE shared longest-first queue.
+
+    ``slots`` (worker threads a rank may run): with it, ``local_pull_fn(pull, workers)`` is called with the number of
+    workers to start, each worker's FIRST item comes from this rank's share of ``queue_plan``'s deterministic deal and
+    the shared counter hands out the rest; without it (``local_pull_fn(pull)``) every pull goes to the counter.
 
     Every rank's workers call ``pull()`` -- a fetch-add on the process group's c10d store (``store.add(key, 1)``,
     no collective) -- for the position in the cost-sorted order of the next item to evaluate; ``pull() < 0`` means
@@ -204,23 +230,39 @@ def queued_map(local_pull_fn: Callable[[Callable[[], int]], Dict[int, Sequence[f
     import itertools
     import threading
     n = len(costs)
-    order = sorted(range(n), key=lambda i: (-costs[i], i))      # longest first, ties by index (same on every rank)
     dist = _dist()
     multi = dist is not None and dist.get_world_size() > 1
+    world = dist.get_world_size() if multi else 1
+    order, workers, heads = queue_plan(costs, world, slots if slots is not None else max(n, 1))
+    if slots is None:
+        workers, head, dealt = None, [], 0          # plain queue: every position through the counter
+    else:
+        head, dealt = list(heads[dist.get_rank() if multi else 0]), sum(len(h) for h in heads)
+    lock = threading.Lock()
     if multi:
         store = _default_store()
 
         def pull() -> int:
-            j = int(store.add(key, 1)) - 1
+            with lock:
+                if head:
+                    return head.pop(0)
+            j = int(store.add(key, 1)) - 1 + dealt
             return order[j] if j < n else -1
     else:
-        ctr, lock = itertools.count(), threading.Lock()
+        ctr = itertools.count()
 
         def pull() -> int:
             with lock:
-                j = next(ctr)
+                if head:
+                    return head.pop(0)
+                j = next(ctr) + dealt
             return order[j] if j < n else -1
-    mine = local_pull_fn(pull) if n else {}
+    if not n:
+        mine = {}
+    elif workers is None:
+        mine = local_pull_fn(pull)
+    else:
+        mine = local_pull_fn(pull, workers)
     local = np.full((n, width + 1), np.nan, dtype=np.float64)
     local[:, width] = 0.0
     for i, row in mine.items():
@@ -300,9 +342,10 @@ class PopulationEvaluator:
         out[:, 0], out[:, 1], out[:, 2], out[:, 3], out[:, 4] = acc, size, fpr, ep, secs
         return out
 
-    def evaluate_genes_pull(self, gene_list: Sequence[Sequence[int]], seeds: Sequence[int], pull: Callable[[], int]) -> Dict[int, np.ndarray]:
-        """Train the candidates ``pull()`` hands to this GPU's worker threads (cfg.n_slots of them call it
-        concurrently, from C++); returns {index: (accuracy, size_mb, fpr, epochs_run, seconds)}."""
+    def evaluate_genes_pull(self, gene_list: Sequence[Sequence[int]], seeds: Sequence[int], pull: Callable[[], int],
+                            workers: Optional[int] = None) -> Dict[int, np.ndarray]:
+        """Train the candidates ``pull()`` hands to this GPU's worker threads (``workers`` of them, default cfg.n_slots,
+        call it concurrently, from C++); returns {index: (accuracy, size_mb, fpr, epochs_run, seconds)}."""
         n = len(gene_list)
         if n == 0:
             return {}
@@ -313,6 +356,8 @@ class PopulationEvaluator:
         acc, size, fpr, secs = (np.zeros(n, np.float64) for _ in range(4))
         ep, done = np.zeros(n, np.int32), np.zeros(n, np.int32)
         cfg, ds = self.config.to_struct(), self._dataset()
+        if workers is not None:
+            cfg.n_slots = max(1, int(workers))
         errors: List[BaseException] = []
 
         def _next(_ctx):
@@ -361,8 +406,9 @@ class PopulationEvaluator:
                                                           np.full((len(idx), 1), rank)], axis=1), costs, 6, device="cuda")
         else:                                       # one longest-first queue drained by all ranks (default)
             rank = float(dist.get_rank())
-            res = queued_map(lambda pull: {i: np.append(r, rank) for i, r in self.evaluate_genes_pull(gl, seeds, pull).items()},
-                             costs, 6, f"{self._queue_prefix}/{self._generation}", device="cuda")
+            res = queued_map(lambda pull, workers: {i: np.append(r, rank)
+                                                    for i, r in self.evaluate_genes_pull(gl, seeds, pull, workers).items()},
+                             costs, 6, f"{self._queue_prefix}/{self._generation}", device="cuda", slots=self.config.n_slots)
         self.last_rank_of = [int(r) for r in res[:, 5]]
         self.evals_done += n
         self.last_epochs_run = [int(e) for e in res[:, 3]]

@@ -81,6 +81,29 @@ def main():
     # (sleep-based simulated time: a few units of absolute slack absorb scheduler jitter on a loaded CI host)
     assert max(tq) <= 1.10 * min(tq) + 4 * unit, f"queue left the ranks unbalanced: {tq}"
     assert max(tq) < 0.9 * static_makespan, f"queue no better than the static split: {tq} vs {static_makespan}"   # ~30.5 vs ~40 units
+    # ---- deterministic head of the queue: with slots, each rank's workers START with the rank's share of queue_plan's
+    # capacity-constrained LPT deal (no race for the large candidates), the counter hands out only the rest
+    from cmoop_audio_processing_amd.evaluator import queue_plan
+    costs_h = [9.0, 1.0, 8.0, 1.0, 7.0, 1.0, 6.0, 1.0, 5.0, 1.0, 1.0]
+    order_h, W_h, heads_h = queue_plan(costs_h, world, 2)
+    assert W_h == 2 and heads_h == [[0, 6], [2, 4]]
+    first = []
+
+    def local_heads(pull, workers):
+        assert workers == W_h
+        mine = {}
+        for k in range(workers):                 # the workers' first pulls, before anything touches the shared counter
+            i = pull()
+            first.append(i)
+            mine[i] = [float(i), float(rank)]
+        dist.barrier()
+        for i in iter(pull, -1):
+            mine[i] = [float(i), float(rank)]
+        return mine
+    out_h = queued_map(local_heads, costs_h, 2, "test/queue/heads", device="cpu", slots=2)
+    assert first == heads_h[rank], (first, heads_h[rank])
+    assert out_h[:, 0].tolist() == [float(i) for i in range(11)]
+    assert [int(out_h[i, 1]) for i in (0, 6)] == [0, 0] and [int(out_h[i, 1]) for i in (2, 4)] == [1, 1]
     # empty generation and fewer candidates than ranks through the queue
     assert queued_map(lambda pull: {}, [], 2, "test/queue/2", device="cpu").shape == (0, 2)
     one = queued_map(lambda pull: {i: [7.0] for i in iter(pull, -1)}, [1.0], 1, "test/queue/3", device="cpu")

@@ -68,7 +68,7 @@ def test_driver_argv_resolves_to_a_bounded_run_with_a_stub_evaluator():
     buf = io.StringIO()
     t0 = time.perf_counter()
     with redirect_stdout(buf):
-        rc = bench.main(["--gpus", "1", "--steps", "20", "--warmup", "5", "--stub", "--stub-ms-per-gflop", "12",
+        rc = bench.main(["--gpus", "1", "--steps", "20", "--warmup", "5", "--stub", "--stub-ms-per-gflop", "100",
                          "--budget-s", "6"], t_origin=time.perf_counter())
     wall = time.perf_counter() - t0
     assert rc == 0 and wall < 7.5, wall            # budget 6 s; the slack absorbs sleep jitter of the stub on a loaded host
@@ -94,7 +94,8 @@ def test_gpus_2_starts_two_ranks_itself_and_reports_them():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["steps"] >= 1
     per_rank = d["config"]["candidates_per_rank_last_step"]
-    assert len(per_rank) == 2 and sum(per_rank) == 40 and min(per_rank) >= 1, per_rank
+    # 8 workers per rank start with the 8 + 8 items of the deterministic deal; the other 24 go through the shared counter
+    assert len(per_rank) == 2 and sum(per_rank) == 40 and min(per_rank) >= 8, per_rank
 
 
 def test_world_size_mismatch_fails_loudly():

@@ -216,3 +216,44 @@ def test_result_packing_matches_every_reference_script(golden_dir):
     assert seen == {"all", "acc_fpr", "acc_size", "size_fpr"}
     with pytest.raises(ValueError):
         pack_result({}, 0.9, 1.0, 0.1, EvalConfig(objectives="nope"))
+
+
+def test_queue_plan_deals_the_first_items_by_capacity_constrained_lpt():
+    """The cross-rank queue's deterministic head (evaluator.queue_plan): with 8 ranks x 8 worker threads a 40-candidate
+    generation would be drained in ONE burst of fetch-adds and the assignment would be a race; instead no rank starts
+    more than ceil(n / world) candidates at once and the items the workers start with are dealt longest-first to the
+    least-loaded rank with a free worker.  bench.py's pop-40 population on 8 ranks: 5 per rank, every candidate dealt,
+    max load within 25 % of the mean (an arbitrary burst can put the 8 largest on one rank: 2-3x the mean)."""
+    import random
+    from cmoop_audio_processing_amd.evaluator import queue_plan
+    rng = random.Random(0)
+    genes = [G.normalize_hparams(G.random_hparams(rng)) for _ in range(40)]
+    costs = [float(G.fwd_flops_per_sample(g, 0, 10, 101, 40)) for g in genes]
+    order, W, heads = queue_plan(costs, 8, 8)
+    assert W == 5 and sorted(i for h in heads for i in h) == list(range(40)) and all(len(h) == 5 for h in heads)
+    assert order == sorted(range(40), key=lambda i: (-costs[i], i))
+    loads = [sum(costs[i] for i in h) for h in heads]
+    assert max(loads) <= 1.25 * (sum(costs) / 8), (max(loads), sum(costs) / 8)
+    assert all(h == sorted(h, key=lambda i: (-costs[i], i)) for h in heads)          # each rank starts its longest first
+    burst = sum(sorted(costs, reverse=True)[:8])                                      # what a race could give one rank
+    assert burst > 2.0 * max(loads)
+    # more candidates than workers: only the first world * W positions are dealt, the rest stays in the shared queue
+    order, W, heads = queue_plan(costs, 2, 8)
+    assert W == 8 and [len(h) for h in heads] == [8, 8] and sorted(i for h in heads for i in h) == sorted(order[:16])
+    # fewer candidates than ranks, one candidate, none
+    assert queue_plan([3.0, 1.0], 4, 8) == ([0, 1], 1, [[0], [1], [], []])
+    assert queue_plan([], 4, 8) == ([], 1, [[], [], [], []])
+    # single process: slots bound the workers, the head is the first W of the order
+    order, W, heads = queue_plan([1.0, 5.0, 2.0], 1, 2)
+    assert (order, W, heads) == ([1, 2, 0], 2, [[1, 2]])
+
+
+def test_queued_map_with_slots_runs_the_workers_it_plans():
+    from cmoop_audio_processing_amd import queued_map
+    seen = {}
+
+    def local(pull, workers):
+        seen["workers"] = workers
+        return {i: [float(i)] for i in iter(pull, -1)}
+    out = queued_map(local, [1.0, 4.0, 2.0, 3.0, 5.0], 1, "unused", slots=3)
+    assert seen["workers"] == 3 and out[:, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
