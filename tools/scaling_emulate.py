@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--slots", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--plan", default="lpt", choices=["lpt", "queue"],
+                    help="lpt: static LPT buckets (schedule='static'); queue: the default schedule's deterministic deal "
+                         "(evaluator.queue_plan) -- only worlds whose whole generation is dealt (n <= world * W) can be emulated, "
+                         "each bucket runs with the W worker threads the rank would use")
     args = ap.parse_args()
 
     import torch
@@ -52,19 +56,30 @@ def main():
     ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
     rng = random.Random(args.seed)
     pop = [G.random_hparams(rng) for _ in range(args.pop)]
-    out = {"pop": args.pop, "n_train": n_tr, "epochs": args.epochs, "slots": args.slots, "worlds": {}}
+    out = {"pop": args.pop, "n_train": n_tr, "epochs": args.epochs, "slots": args.slots, "plan": args.plan, "worlds": {}}
     t1 = None
     gl = [G.normalize_hparams(hp) for hp in pop]
     costs = [float(G.fwd_flops_per_sample(g, G.VARIANT_A, args.classes, ev.T, ev.F)) for g in gl]
     for world in [int(w) for w in args.worlds.split(",")]:
-        buckets = G.lpt_assign(costs, world)        # the same assignment sharded_map makes on every rank
+        ev_w = ev
+        if args.plan == "queue" and world > 1:
+            from dataclasses import replace
+            from cmoop_audio_processing_amd.evaluator import queue_plan
+            _, W, buckets = queue_plan(costs, world, args.slots)
+            if sum(len(b) for b in buckets) != len(gl):
+                print(f"[emulate] world {world}: {len(gl) - sum(len(b) for b in buckets)} candidates would go through the "
+                      "shared counter; not emulated", file=sys.stderr, flush=True)
+                continue
+            ev_w = PopulationEvaluator(Xtr, ytr, Xva, yva, replace(cfg, n_slots=W))
+        else:
+            buckets = G.lpt_assign(costs, world)        # the same assignment sharded_map makes on every rank
         times = []
         for r, idx in enumerate(buckets):
             sub = [gl[i] for i in idx]
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if sub:
-                ev.evaluate_genes(sub, [args.seed + i for i in idx])
+                ev_w.evaluate_genes(sub, [args.seed + i for i in idx])
             torch.cuda.synchronize()
             times.append(round(time.perf_counter() - t0, 3))
             print(f"[emulate] world {world} rank {r}: {len(sub)} candidates, {times[-1]} s", file=sys.stderr, flush=True)
