@@ -98,6 +98,21 @@ def test_gpus_2_starts_two_ranks_itself_and_reports_them():
     assert len(per_rank) == 2 and sum(per_rank) == 40 and min(per_rank) >= 8, per_rank
 
 
+def test_gpus_8_rehearsal_deals_five_candidates_to_every_rank():
+    """The driver's 8-rank launch, rehearsed with the stub evaluator over gloo on the CPU: bench.py starts its 8 ranks,
+    every rank runs min(8, ceil(40 / 8)) = 5 workers and gets exactly the 5 candidates of the deterministic deal
+    (evaluator.queue_plan) -- no burst of fetch-adds decides who trains the large ones."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--stub", "--steps", "2", "--warmup", "1",
+                        "--budget-s", "60", "--stub-ms-per-gflop", "6"], capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["steps"] >= 1
+    assert d["config"]["candidates_per_rank_last_step"] == [5] * 8
+
+
 def test_world_size_mismatch_fails_loudly():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], capture_output=True, text=True,
