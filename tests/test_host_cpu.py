@@ -257,3 +257,19 @@ def test_queued_map_with_slots_runs_the_workers_it_plans():
         return {i: [float(i)] for i in iter(pull, -1)}
     out = queued_map(local, [1.0, 4.0, 2.0, 3.0, 5.0], 1, "unused", slots=3)
     assert seen["workers"] == 3 and out[:, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
+def test_shape_time_share_tool_walks_the_same_layers_as_the_model():
+    """tools/shape_time_share.py (where the generation's GEMM time goes, by layer shape) re-derives the conv stack of
+    topology A from the gene; it must list exactly the convs genes.layer_specs describes (minus the C_in = 1 first conv)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("shape_time_share", os.path.join(ROOT, "tools", "shape_time_share.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for g in G.all_genes():
+        ours = [(ci, co, k, st) for (_, _, ci, co, k, st, _) in mod.conv_shapes(g)]
+        ref = [(l["cin"], l["cout"], l["k"], l["stride"]) for l in G.layer_specs(g, G.VARIANT_A, 10) if l["kind"] == "conv"][1:]
+        assert ours == ref, g
+    # spatial sizes: SAME pools halve with ceil (101x40 -> 51x20 -> 26x10 -> 13x5)
+    assert [(h, w) for (h, w, *_rest) in mod.conv_shapes((16, 3, 0, 3, 1, 0))] == \
+           [(101, 40)] + [(51, 20)] * 3 + [(26, 10)] * 3 + [(13, 5)] * 3
