@@ -97,6 +97,35 @@ def default_config() -> Config:
     return c
 
 
+def last_kernels():
+    """Launch-path variant names of the GEMM kernels the calling thread's last kernel-level call launched."""
+    buf = C.create_string_buffer(1024)
+    check(lib().cmoop_last_kernels(buf, C.c_int32(1024)))
+    return [k for k in buf.value.decode().split(";") if k]
+
+
+def profile_entries():
+    """[(kernel name, launches, total ms, total flops)] of the HIP-event-sampled MFMA GEMM launches."""
+    L, cnt, out = lib(), C.c_int32(), []
+    check(L.cmoop_profile_count(C.byref(cnt)))
+    for i in range(cnt.value):
+        name, n, ms, fl = C.create_string_buffer(160), C.c_int64(), C.c_double(), C.c_double()
+        check(L.cmoop_profile_entry(i, name, 160, C.byref(n), C.byref(ms), C.byref(fl)))
+        out.append((name.value.decode(), int(n.value), float(ms.value), float(fl.value)))
+    return out
+
+
+def profile_variants():
+    """Launch-path variants (instantiation + "+sk" / "+stats" / "+tab" / "+slabs") of the sampled launches."""
+    L, cnt, out = lib(), C.c_int32(), []
+    check(L.cmoop_profile_variant_count(C.byref(cnt)))
+    for i in range(cnt.value):
+        name = C.create_string_buffer(200)
+        check(L.cmoop_profile_variant(i, name, 200))
+        out.append(name.value.decode())
+    return out
+
+
 def ptr(t):
     """Raw device/host pointer of a torch tensor or numpy array (must be contiguous)."""
     if t is None:

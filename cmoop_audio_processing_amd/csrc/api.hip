@@ -9,6 +9,7 @@
 using namespace cmoop;
 
 static thread_local std::string g_err;
+static thread_local std::string g_last_kernels;   // cmoop_last_kernels
 
 template <class F>
 static int guard(F&& f) {
@@ -75,6 +76,18 @@ static ConvGeom make_geom(int B, int H, int W, int Cin, int Cout, int KS, int st
     return g;
 }
 
+// records the launch-path variant names of the GEMM launches a kernel-level call makes (cmoop_last_kernels)
+struct RecordingHook : GemmHook {
+    int cls = 0;
+    std::string* out;
+    explicit RecordingHook(std::string* o) : out(o) {}
+    const GemmTiming* begin(int c, double) override { cls = c; return nullptr; }
+    void end(int code, int flags) override {
+        if (!out->empty()) *out += ";";
+        *out += gemm_variant_name(cls, code, flags);
+    }
+};
+
 extern "C" {
 
 int cmoop_abi_version(void) { return CMOOP_ABI_VERSION; }
@@ -108,6 +121,7 @@ int cmoop_eval_population(const cmoop_config* cfg, const cmoop_dataset* ds, cons
         d.x_train = ds->x_train; d.y_train = ds->y_train; d.n_train = ds->n_train;
         d.x_val = ds->x_val; d.y_val = ds->y_val; d.n_val = ds->n_val; d.T = ds->T; d.F = ds->F;
         CMOOP_REQUIRE(n == 0 || (d.x_train && d.y_train && d.x_val && d.y_val), "dataset pointers are NULL");
+        for (int i = 0; i < n; ++i) check_plan_ranges(genes + 6 * i, c.variant, d.T, d.F, std::max(c.batch, c.eval_batch));
         std::vector<EvalResult> r(n);
         eval_population(c, d, genes, seeds, n, r.data());
         for (int i = 0; i < n; ++i) {
@@ -132,6 +146,7 @@ int cmoop_eval_population_pull(const cmoop_config* cfg, const cmoop_dataset* ds,
         d.x_train = ds->x_train; d.y_train = ds->y_train; d.n_train = ds->n_train;
         d.x_val = ds->x_val; d.y_val = ds->y_val; d.n_val = ds->n_val; d.T = ds->T; d.F = ds->F;
         CMOOP_REQUIRE(n == 0 || (d.x_train && d.y_train && d.x_val && d.y_val), "dataset pointers are NULL");
+        for (int i = 0; i < n; ++i) check_plan_ranges(genes + 6 * i, c.variant, d.T, d.F, std::max(c.batch, c.eval_batch));
         std::vector<EvalResult> r(n);
         eval_population(c, d, genes, seeds, n, r.data(), [&]() { return (int)next(ctx); });
         for (int i = 0; i < n; ++i) {
@@ -143,6 +158,37 @@ int cmoop_eval_population_pull(const cmoop_config* cfg, const cmoop_dataset* ds,
             if (val_loss) val_loss[i] = r[i].val_loss;
             if (seconds) seconds[i] = r[i].seconds;
         }
+    });
+}
+
+int cmoop_plan_check(const int32_t gene[6], int32_t variant, int32_t T, int32_t F, int32_t batch) {
+    return guard([&] {
+        CMOOP_REQUIRE(gene && (variant == 0 || variant == 1) && T >= 1 && F >= 1 && batch >= 1, "plan_check: bad arguments");
+        check_plan_ranges(gene, variant, T, F, batch);
+    });
+}
+
+int cmoop_conv_launch_plan(int32_t op, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride,
+                           int32_t want_stats, char* name, int32_t name_cap) {
+    return guard([&] {
+        CMOOP_REQUIRE(name && name_cap > 0 && op >= 0 && op <= 2, "launch_plan: bad arguments");
+        CMOOP_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 16 && Cout >= 1 && KS >= 1 && stride >= 1, "bad conv shape");
+        const ConvGeom g = make_geom(B, H, W, Cin, Cout, KS, stride);
+        const bool tab = KS * KS <= 32;              // Net::build_plan builds the layer's row tables under this condition
+        int flags = 0, code = 0, cls = 0;
+        GemmEpilogue e;
+        if (op == 0) {
+            code = igemm_fwd_plan(g, e, igemm_splitk_workspace(g), want_stats != 0, tab, &flags);
+        } else if (op == 1) {
+            CMOOP_REQUIRE(ilog2_exact(Cout) >= 4, "launch_plan: the dgrad of this layer does not run on the MFMA kernel");
+            const ConvGeom gd = dgrad_geometry(g);
+            if (stride != 1) { e.out_stride = stride; e.OHf = H; e.OWf = W; e.accumulate = 1; }
+            code = igemm_fwd_plan(gd, e, igemm_splitk_workspace(gd), false, tab, &flags);
+        } else {
+            cls = 1;
+            code = igemm_wgrad_plan(g, wgrad_slices(g), GEMM_DEFAULT, tab, &flags);
+        }
+        std::snprintf(name, name_cap, "%s", gemm_variant_name(cls, code, flags).c_str());
     });
 }
 
@@ -239,6 +285,24 @@ int cmoop_profile_entry(int32_t i, char* name, int32_t name_cap, int64_t* launch
     });
 }
 
+int cmoop_profile_variant_count(int32_t* out) {
+    return guard([&] {
+        ProfileTotals& t = profile_totals();
+        std::lock_guard<std::mutex> l(t.mu);
+        *out = (int32_t)t.variants.size();
+    });
+}
+int cmoop_profile_variant(int32_t i, char* name, int32_t name_cap) {
+    return guard([&] {
+        ProfileTotals& t = profile_totals();
+        std::lock_guard<std::mutex> l(t.mu);
+        CMOOP_REQUIRE(i >= 0 && i < (int)t.variants.size() && name_cap > 0, "profile variant out of range");
+        auto it = t.variants.begin();
+        std::advance(it, i);
+        std::snprintf(name, name_cap, "%s", it->c_str());
+    });
+}
+
 // ---- session -------------------------------------------------------------------
 struct cmoop_net {
     Net* net;
@@ -273,6 +337,62 @@ int cmoop_net_train_step(cmoop_net* h, const float* x, const int32_t* y, const i
     return guard([&] {
         h->net->train_step(x, y, idx, row0, B);
         CMOOP_HIP(hipStreamSynchronize(h->net->stream()));
+        h->net->drain_profile();     // cfg.profile_every > 0: the sampled launches enter cmoop_profile_entry / _variant
+    });
+}
+int cmoop_net_get_state(cmoop_net* h, float* params, float* adam_m, float* adam_v, int64_t* iterations, int64_t* steps) {
+    return guard([&] {
+        long long it = 0, st = 0;
+        h->net->get_state(params, adam_m, adam_v, &it, &st);
+        if (iterations) *iterations = it;
+        if (steps) *steps = st;
+    });
+}
+int cmoop_net_set_state(cmoop_net* h, const float* params, const float* adam_m, const float* adam_v, int64_t iterations,
+                        int64_t steps) {
+    return guard([&] { h->net->set_state(params, adam_m, adam_v, iterations, steps); });
+}
+int cmoop_net_set_gather_rows(cmoop_net* h, int64_t n_rows) {
+    return guard([&] {
+        CMOOP_REQUIRE(n_rows >= 0, "negative row count");
+        h->net->set_gather_rows(n_rows);
+    });
+}
+int cmoop_net_run_epoch(cmoop_net* h, const float* x, const int32_t* y, int64_t n_train, int32_t epoch) {
+    return guard([&] {
+        CMOOP_REQUIRE(x && y && n_train >= 1, "run_epoch: NULL / empty training split");
+        int32_t* idx = static_cast<int32_t*>(pool_alloc((size_t)n_train * 4));
+        try {
+            h->net->run_epoch(x, y, n_train, epoch, idx);
+            CMOOP_HIP(hipStreamSynchronize(h->net->stream()));
+            h->net->drain_profile();
+        } catch (...) {
+            hipStreamSynchronize(h->net->stream());
+            pool_free(idx);
+            throw;
+        }
+        pool_free(idx);
+    });
+}
+int cmoop_net_fit(cmoop_net* h, const cmoop_dataset* ds, int32_t hist_cap, double* val_loss_hist, double* val_acc_hist,
+                  int32_t* epochs_run, int32_t* best_epoch, double* acc, double* fpr, double* val_loss) {
+    return guard([&] {
+        CMOOP_REQUIRE(ds && ds->x_train && ds->y_train && ds->x_val && ds->y_val, "fit: dataset pointers are NULL");
+        Dataset d;
+        d.x_train = ds->x_train; d.y_train = ds->y_train; d.n_train = ds->n_train;
+        d.x_val = ds->x_val; d.y_val = ds->y_val; d.n_val = ds->n_val; d.T = ds->T; d.F = ds->F;
+        CMOOP_REQUIRE(d.T == h->net->feature_T() && d.F == h->net->feature_F(), "fit: dataset feature shape differs from the net's");
+        FitHistory hist;
+        const EvalResult r = fit_and_read_out(*h->net, h->net->config(), d, h->net->seed(), &hist);
+        for (int i = 0; i < hist_cap && i < (int)hist.val_loss.size(); ++i) {
+            if (val_loss_hist) val_loss_hist[i] = hist.val_loss[i];
+            if (val_acc_hist) val_acc_hist[i] = hist.val_acc[i];
+        }
+        if (epochs_run) *epochs_run = r.epochs_run;
+        if (best_epoch) *best_epoch = hist.best_epoch;
+        if (acc) *acc = r.acc;
+        if (fpr) *fpr = r.fpr;
+        if (val_loss) *val_loss = r.val_loss;
     });
 }
 int cmoop_net_evaluate(cmoop_net* h, const float* x, const int32_t* y, int64_t n, double* loss_sum, int64_t* correct,
@@ -307,6 +427,7 @@ int cmoop_epoch_permutation_device(uint32_t seed, uint32_t epoch, int64_t n, int
 int cmoop_conv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t H, int32_t W, int32_t Cin,
                    int32_t Cout, int32_t KS, int32_t stride, int32_t relu) {
     return guard([&] {
+        g_last_kernels.clear();
         hipStream_t s = lib_stream();
         if (Cin == 1) {
             CMOOP_REQUIRE(stride == 1 && bias, "first-layer conv: stride 1 with bias");
@@ -318,7 +439,9 @@ int cmoop_conv_fwd(const float* x, const float* w, const float* bias, float* y, 
             const size_t skf = igemm_splitk_workspace(g);
             float* sk = nullptr;
             if (skf) CMOOP_HIP(hipMalloc(&sk, skf * 4));
-            launch_igemm_fwd(x, w, y, g, e, s, nullptr, sk, skf);
+            int flags = 0;
+            const int code = launch_igemm_fwd(x, w, y, g, e, s, nullptr, sk, skf, nullptr, nullptr, 0, &flags);
+            g_last_kernels = gemm_variant_name(0, code, flags);
             CMOOP_HIP(hipStreamSynchronize(s));
             if (sk) hipFree(sk);
         }
@@ -356,7 +479,9 @@ int cmoop_conv_bwd(const float* x, const float* w, const float* dy, float* dx, f
             CMOOP_HIP(hipMalloc(&tab, (size_t)tab_rows * 8));
             launch_build_rowtab(g, tab, s);
         }
-        conv_backward_weights(x, dy, dw, db, g, wg, wg_floats, s, nullptr, GEMM_DEFAULT, tab, tab_rows);
+        g_last_kernels.clear();
+        RecordingHook hook(&g_last_kernels);
+        conv_backward_weights(x, dy, dw, db, g, wg, wg_floats, s, &hook, GEMM_DEFAULT, tab, tab_rows);
         if (dx) {
             int accumulate = 0;
             if (stride != 1) {
@@ -367,12 +492,138 @@ int cmoop_conv_bwd(const float* x, const float* w, const float* dy, float* dx, f
             gd.H = g.OH; gd.W = g.OW; gd.Cin = g.Cout; gd.Cout = g.Cin; gd.OH = g.H; gd.OW = g.W;
             const size_t skf = (stride == 1 && Cout >= 16 && (Cout & (Cout - 1)) == 0) ? igemm_splitk_workspace(gd) : 0;
             if (skf) CMOOP_HIP(hipMalloc(&sk, skf * 4));
-            conv_backward_data(dy, w, dx, g, wd, mask_relu ? x : nullptr, 1.f, accumulate, s, nullptr, sk, skf);
+            conv_backward_data(dy, w, dx, g, wd, mask_relu ? x : nullptr, 1.f, accumulate, s, &hook, sk, skf);
         }
         CMOOP_HIP(hipStreamSynchronize(s));
         hipFree(wg); hipFree(red); hipFree(wd);
         if (sk) hipFree(sk);
         if (tab) hipFree(tab);
+    });
+}
+
+// ---- the same two operations launched as the trainer launches them -------------------
+// ---- the same two operations launched as the trainer launches them -------------------
+int cmoop_conv_fwd_trainer(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t H, int32_t W,
+                           int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t relu, double* col_sum,
+                           double* col_sumsq, int32_t* stats_fused) {
+    return guard([&] {
+        g_last_kernels.clear();
+        hipStream_t s = lib_stream();
+        const ConvGeom g = make_geom(B, H, W, Cin, Cout, KS, stride);
+        const int64_t M = g.M();
+        GemmEpilogue e;
+        e.bias = bias; e.relu = relu;
+        float *sk = nullptr, *red = nullptr;
+        void* tab = nullptr;
+        const size_t skf = igemm_splitk_workspace(g);
+        const bool want_stats = col_sum != nullptr && col_sumsq != nullptr;
+        CMOOP_REQUIRE(!want_stats || Cout % 4 == 0, "statistics need Cout % 4 == 0");
+        auto cleanup = [&] { hipStreamSynchronize(s); if (sk) hipFree(sk); if (red) hipFree(red); if (tab) hipFree(tab); };
+        try {
+            if (skf) CMOOP_HIP(hipMalloc(&sk, skf * 4));
+            const int tab_rows = (KS * KS <= 32) ? rowtab_rows(g) : 0;     // Net::build_plan's condition
+            if (tab_rows) {
+                CMOOP_HIP(hipMalloc(&tab, (size_t)tab_rows * 8));
+                launch_build_rowtab(g, tab, s);
+            }
+            size_t red_floats = 0;
+            if (want_stats) {   // Net::build_plan's sizing of the statistics partials
+                const size_t blocks = std::max<size_t>((size_t)colreduce_blocks(M, Cout), (size_t)cdiv64(M, 64));
+                red_floats = blocks * 2 * Cout + 2 * Cout;
+                CMOOP_HIP(hipMalloc(&red, red_floats * 4));
+                e.stats = red;
+            }
+            int nb = 0, flags = 0;
+            const int code = launch_igemm_fwd(x, w, y, g, e, s, nullptr, sk, skf, want_stats ? &nb : nullptr, tab, tab_rows, &flags);
+            g_last_kernels = gemm_variant_name(0, code, flags);
+            if (want_stats) {
+                if (stats_fused) *stats_fused = nb > 0 ? 1 : 0;
+                if (nb == 0) {          // split-K launch: the trainer falls back to the stand-alone reduction
+                    nb = colreduce_blocks(M, Cout);
+                    launch_colstats(y, red, M, Cout, nb, s);
+                }
+                std::vector<float> hp((size_t)nb * 2 * Cout);
+                CMOOP_HIP(hipMemcpyAsync(hp.data(), red, hp.size() * 4, hipMemcpyDeviceToHost, s));
+                CMOOP_HIP(hipStreamSynchronize(s));
+                for (int c = 0; c < Cout; ++c) { col_sum[c] = 0.0; col_sumsq[c] = 0.0; }
+                for (int b = 0; b < nb; ++b)
+                    for (int c = 0; c < Cout; ++c) {
+                        col_sum[c] += (double)hp[((size_t)b * 2) * Cout + c];
+                        col_sumsq[c] += (double)hp[((size_t)b * 2 + 1) * Cout + c];
+                    }
+            }
+            CMOOP_HIP(hipStreamSynchronize(s));
+        } catch (...) {
+            cleanup();
+            throw;
+        }
+        cleanup();
+    });
+}
+
+int cmoop_conv_bwd_trainer(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t B, int32_t H,
+                           int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t mask_relu) {
+    return guard([&] {
+        g_last_kernels.clear();
+        hipStream_t s = lib_stream();
+        const ConvGeom g = make_geom(B, H, W, Cin, Cout, KS, stride);
+        float *wg = nullptr, *wd = nullptr, *sk = nullptr, *dwb = nullptr;
+        void *tab = nullptr, *tab_d = nullptr;
+        auto cleanup = [&] {
+            hipStreamSynchronize(s);
+            if (wg) hipFree(wg); if (wd) hipFree(wd); if (sk) hipFree(sk); if (dwb) hipFree(dwb); if (tab) hipFree(tab); if (tab_d) hipFree(tab_d);
+        };
+        try {
+            RecordingHook hook(&g_last_kernels);
+            const size_t NK = (size_t)g.Cout * g.K();
+            const size_t wg_floats = (size_t)wgrad_slices(g) * g.Cout * (g.K() + 1);
+            CMOOP_HIP(hipMalloc(&wg, wg_floats * 4));
+            CMOOP_HIP(hipMalloc(&dwb, (NK + g.Cout) * 4));          // the trainer's arena layout: bias gradient directly after the kernel gradient
+            const int tab_rows = (KS * KS <= 32) ? rowtab_rows(g) : 0;
+            if (tab_rows) {
+                CMOOP_HIP(hipMalloc(&tab, (size_t)tab_rows * 8));
+                launch_build_rowtab(g, tab, s);
+            }
+            conv_backward_weights(x, dy, dwb, dwb + NK, g, wg, wg_floats, s, &hook, GEMM_DEFAULT, tab, tab_rows);
+            CMOOP_HIP(hipMemcpyAsync(dw, dwb, NK * 4, hipMemcpyDeviceToDevice, s));
+            CMOOP_HIP(hipMemcpyAsync(db, dwb + NK, (size_t)g.Cout * 4, hipMemcpyDeviceToDevice, s));
+            if (dx) {
+                int accumulate = 0;
+                if (stride != 1) {
+                    CMOOP_HIP(hipMemsetAsync(dx, 0, (size_t)B * H * W * Cin * 4, s));
+                    accumulate = 1;
+                }
+                const bool mfma_dgrad = ilog2_exact(Cout) >= 4;
+                const ConvGeom gd = dgrad_geometry(g);
+                int tab_d_rows = 0;
+                size_t skf = 0;
+                if (mfma_dgrad) {
+                    CMOOP_HIP(hipMalloc(&wd, NK * 4));
+                    launch_flip_transpose(w, wd, Cout, KS, KS, Cin, s);       // the trainer's one-launch-per-step refresh, for one layer
+                    if (KS * KS <= 32) {
+                        tab_d_rows = rowtab_rows(gd);
+                        CMOOP_HIP(hipMalloc(&tab_d, (size_t)tab_d_rows * 8));
+                        launch_build_rowtab(gd, tab_d, s);
+                    }
+                    skf = igemm_splitk_workspace(gd);      // the trainer passes its workspace to every dgrad, the skip projection's too
+                    if (skf) CMOOP_HIP(hipMalloc(&sk, skf * 4));
+                }
+                conv_backward_data(dy, w, dx, g, wd, mask_relu ? x : nullptr, 1.f, accumulate, s, &hook, sk, skf, GEMM_DEFAULT, mfma_dgrad,
+                                   tab_d, tab_d_rows);
+            }
+            CMOOP_HIP(hipStreamSynchronize(s));
+        } catch (...) {
+            cleanup();
+            throw;
+        }
+        cleanup();
+    });
+}
+
+int cmoop_last_kernels(char* buf, int32_t cap) {
+    return guard([&] {
+        CMOOP_REQUIRE(buf && cap > 0, "last_kernels: no buffer");
+        std::snprintf(buf, cap, "%s", g_last_kernels.c_str());
     });
 }
 
@@ -427,6 +678,22 @@ int cmoop_conv_time(int32_t mode, const float* x, const float* w, const float* b
     });
 }
 
+int cmoop_dense_fwd(const float* x, const float* w, const float* bias, float* y, int32_t M, int32_t N, int32_t K, int32_t relu) {
+    return guard([&] {
+        hipStream_t s = lib_stream();
+        launch_dense_fwd(x, w, bias, y, M, N, K, relu, 0, 0u, 0u, 1.f, GEMM_DEFAULT, s);
+        CMOOP_HIP(hipStreamSynchronize(s));
+    });
+}
+int cmoop_dense_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t M, int32_t N, int32_t K,
+                    int32_t mask_relu) {
+    return guard([&] {
+        hipStream_t s = lib_stream();
+        launch_dense_wgrad(x, dy, dw, db, M, N, K, GEMM_DEFAULT, s);
+        if (dx) launch_dense_dgrad(dy, w, dx, M, N, K, mask_relu ? x : nullptr, 1.f, GEMM_DEFAULT, s);
+        CMOOP_HIP(hipStreamSynchronize(s));
+    });
+}
 int cmoop_maxpool_fwd(const float* x, float* y, uint8_t* arg, int32_t B, int32_t H, int32_t W, int32_t C) {
     return guard([&] {
         hipStream_t s = lib_stream();

@@ -9,6 +9,14 @@ namespace cmoop {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// row of the resident tensor a batch position maps to: idx[pos] (the epoch permutation) or pos itself; with n_rows > 0
+// the result is clamped into [0, n_rows): a corrupt index can then mis-train but never fault
+__device__ __forceinline__ int64_t gather_row(const int32_t* __restrict__ idx, int64_t pos, int64_t n_rows) {
+    int64_t src = idx ? (int64_t)idx[pos] : pos;
+    if (n_rows > 0) src = src < 0 ? 0 : (src >= n_rows ? n_rows - 1 : src);
+    return src;
+}
+
 // ===========================================================================
 // first layer: C_in = 1 direct conv (Keras Conv2D(filters, k, padding='same') on
 // the (T,F,1) input, nsga_penalty.py:255 / sa_nsga_penalty.py:151)
@@ -19,7 +27,8 @@ template <int KS>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx,
                                                         int64_t row0, const float* __restrict__ Wt,
                                                         const float* __restrict__ bias, float* __restrict__ Y, int B,
-                                                        int H, int W, int Cout, int relu, const StepState* __restrict__ st) {
+                                                        int H, int W, int Cout, int relu, const StepState* __restrict__ st,
+                                                        int64_t n_rows) {
     constexpr int TAPS = KS * KS, SEG = 4 + KS - 1, p = (KS - 1) >> 1;
     __shared__ __attribute__((aligned(16))) float Ws[TAPS * 64];
     if (st) row0 = st->row0;
@@ -36,7 +45,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     if (group >= (int64_t)B * H * W4) return;
     const int b = (int)(group / (H * W4)), r = (int)(group - (int64_t)b * H * W4);
     const int h = r / W4, w0 = (r - h * W4) * 4;
-    const int64_t src = idx ? (int64_t)idx[row0 + b] : row0 + b;
+    const int64_t src = gather_row(idx, row0 + b, n_rows);
     const float* xb = X + src * (int64_t)H * W;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
     f32x4 acc[4] = {bv, bv, bv, bv};
@@ -72,14 +81,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 }
 
 void launch_conv1_fwd(const float* X, const int32_t* idx, int64_t row0, const float* Wt, const float* bias, float* Y,
-                      int B, int H, int W, int Cout, int KS, int relu, hipStream_t s, const StepState* st) {
+                      int B, int H, int W, int Cout, int KS, int relu, hipStream_t s, const StepState* st, int64_t n_rows) {
     CMOOP_REQUIRE(Cout % 4 == 0 && Cout <= 64 && 64 % (Cout / 4) == 0 && (KS == 3 || KS == 5), "conv1: unsupported shape");
     const int GPB = 256 / (Cout / 4);
     const int64_t groups = (int64_t)B * H * ((W + 3) / 4);
     if (groups == 0) return;
     const dim3 grid((unsigned)cdiv64(groups, GPB));
-    if (KS == 3) hipLaunchKernelGGL(conv1_fwd_kernel<3>, grid, dim3(256), 0, s, X, idx, row0, Wt, bias, Y, B, H, W, Cout, relu, st);
-    else hipLaunchKernelGGL(conv1_fwd_kernel<5>, grid, dim3(256), 0, s, X, idx, row0, Wt, bias, Y, B, H, W, Cout, relu, st);
+    if (KS == 3) hipLaunchKernelGGL(conv1_fwd_kernel<3>, grid, dim3(256), 0, s, X, idx, row0, Wt, bias, Y, B, H, W, Cout, relu, st, n_rows);
+    else hipLaunchKernelGGL(conv1_fwd_kernel<5>, grid, dim3(256), 0, s, X, idx, row0, Wt, bias, Y, B, H, W, Cout, relu, st, n_rows);
     CMOOP_HIP(hipGetLastError());
 }
 
@@ -94,7 +103,7 @@ template <int KS>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx,
                                                           int64_t row0, const float* __restrict__ dY,
                                                           float* __restrict__ P, int B, int H, int W, int Cout,
-                                                          const StepState* __restrict__ st) {
+                                                          const StepState* __restrict__ st, int64_t n_rows) {
     constexpr int TAPS = KS * KS, SEG = 4 + KS - 1, p = (KS - 1) >> 1;
     __shared__ float red[4 * (TAPS + 1) * 64];
     if (st) row0 = st->row0;
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     for (int64_t group = (int64_t)blockIdx.x * GPB + gl; group < groups; group += (int64_t)gridDim.x * GPB) {
         const int b = (int)(group / (H * W4)), r = (int)(group - (int64_t)b * H * W4);
         const int h = r / W4, w0 = (r - h * W4) * 4;
-        const int64_t src = idx ? (int64_t)idx[row0 + b] : row0 + b;
+        const int64_t src = gather_row(idx, row0 + b, n_rows);
         const float* xb = X + src * (int64_t)H * W;
         const int64_t pix0 = ((int64_t)b * H + h) * W + w0;
         f32x4 dy[4];
@@ -182,7 +191,7 @@ template <int KS, int NCH, int U>
 __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx,
                                                                int64_t row0, const float* __restrict__ dY,
                                                                float* __restrict__ P, int H, int W, int RC,
-                                                               const StepState* __restrict__ st) {
+                                                               const StepState* __restrict__ st, int64_t n_rows) {
     constexpr int TAPS = KS * KS, TT = (TAPS + 1 + 15) / 16, pad = (KS - 1) >> 1, Cout = 16 * NCH;
     typedef float dyvec __attribute__((ext_vector_type(NCH)));
     __shared__ __attribute__((aligned(16))) float red[3 * TT * NCH * 256];
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const float* __re
     const int b = blockIdx.x / RC, rc = blockIdx.x - b * RC;
     const int rows_per = (H + RC - 1) / RC;
     const int h_begin = rc * rows_per, h_end = min(H, h_begin + rows_per);
-    const int64_t src = idx ? (int64_t)idx[row0 + b] : row0 + b;
+    const int64_t src = gather_row(idx, row0 + b, n_rows);
     const float* xb = X + src * (int64_t)H * W;
     const float* dyb = dY + (int64_t)b * H * W * Cout + NCH * lr;
     int dh[TT], dw[TT], kind[TT];   // kind 0: a real tap (input shifted by dh, dw); 1: the bias row (input 1); 2: unused row
@@ -273,39 +282,39 @@ __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const float* __re
 
 template <int KS, int NCH>
 static void launch_conv1_wgrad_mfma(const float* X, const int32_t* idx, int64_t row0, const float* dY, float* P, int B, int H,
-                                    int W, hipStream_t s, const StepState* st) {
+                                    int W, hipStream_t s, const StepState* st, int64_t n_rows) {
     const int RC = conv1_row_chunks(B, H), W4 = (W + 3) / 4;
     const dim3 grid((unsigned)(B * RC));
     // groups of 4 pixels per row, U at a time: pick the U that wastes no masked group (W = 40: 10 groups = 2 x 5)
     if (W4 % 5 == 0)
-        hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<KS, NCH, 5>), grid, dim3(256), 0, s, X, idx, row0, dY, P, H, W, RC, st);
+        hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<KS, NCH, 5>), grid, dim3(256), 0, s, X, idx, row0, dY, P, H, W, RC, st, n_rows);
     else if (W4 % 3 == 0 && W4 % 4 != 0)
-        hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<KS, NCH, 3>), grid, dim3(256), 0, s, X, idx, row0, dY, P, H, W, RC, st);
+        hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<KS, NCH, 3>), grid, dim3(256), 0, s, X, idx, row0, dY, P, H, W, RC, st, n_rows);
     else
-        hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<KS, NCH, 4>), grid, dim3(256), 0, s, X, idx, row0, dY, P, H, W, RC, st);
+        hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<KS, NCH, 4>), grid, dim3(256), 0, s, X, idx, row0, dY, P, H, W, RC, st, n_rows);
 }
 
 void launch_conv1_wgrad(const float* X, const int32_t* idx, int64_t row0, const float* dY, float* P, int B, int H,
-                        int W, int Cout, int KS, hipStream_t s, const StepState* st) {
+                        int W, int Cout, int KS, hipStream_t s, const StepState* st, int64_t n_rows) {
     CMOOP_REQUIRE(Cout % 4 == 0 && Cout <= 64 && 64 % (Cout / 4) == 0, "conv1 wgrad: unsupported Cout");
     if (B == 0) return;
     if ((Cout == 16 || Cout == 32 || Cout == 64) && (KS == 3 || KS == 5)) {
         const int nch = Cout / 16;
         if (KS == 3) {
-            if (nch == 1) launch_conv1_wgrad_mfma<3, 1>(X, idx, row0, dY, P, B, H, W, s, st);
-            else if (nch == 2) launch_conv1_wgrad_mfma<3, 2>(X, idx, row0, dY, P, B, H, W, s, st);
-            else launch_conv1_wgrad_mfma<3, 4>(X, idx, row0, dY, P, B, H, W, s, st);
+            if (nch == 1) launch_conv1_wgrad_mfma<3, 1>(X, idx, row0, dY, P, B, H, W, s, st, n_rows);
+            else if (nch == 2) launch_conv1_wgrad_mfma<3, 2>(X, idx, row0, dY, P, B, H, W, s, st, n_rows);
+            else launch_conv1_wgrad_mfma<3, 4>(X, idx, row0, dY, P, B, H, W, s, st, n_rows);
         } else {
-            if (nch == 1) launch_conv1_wgrad_mfma<5, 1>(X, idx, row0, dY, P, B, H, W, s, st);
-            else if (nch == 2) launch_conv1_wgrad_mfma<5, 2>(X, idx, row0, dY, P, B, H, W, s, st);
-            else launch_conv1_wgrad_mfma<5, 4>(X, idx, row0, dY, P, B, H, W, s, st);
+            if (nch == 1) launch_conv1_wgrad_mfma<5, 1>(X, idx, row0, dY, P, B, H, W, s, st, n_rows);
+            else if (nch == 2) launch_conv1_wgrad_mfma<5, 2>(X, idx, row0, dY, P, B, H, W, s, st, n_rows);
+            else launch_conv1_wgrad_mfma<5, 4>(X, idx, row0, dY, P, B, H, W, s, st, n_rows);
         }
         CMOOP_HIP(hipGetLastError());
         return;
     }
     const int nb = conv1_wgrad_blocks(B, H, W);
-    if (KS == 3) hipLaunchKernelGGL(conv1_wgrad_kernel<3>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout, st);
-    else if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_kernel<5>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout, st);
+    if (KS == 3) hipLaunchKernelGGL(conv1_wgrad_kernel<3>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout, st, n_rows);
+    else if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_kernel<5>, dim3(nb), dim3(256), 0, s, X, idx, row0, dY, P, B, H, W, Cout, st, n_rows);
     else CMOOP_REQUIRE(false, "conv1 wgrad: kernel size must be 3 or 5");
     CMOOP_HIP(hipGetLastError());
 }
@@ -925,7 +934,8 @@ void launch_gap_bwd(const float* dY, const float* X, float* dX, int B, int HW, i
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ Z, const int32_t* __restrict__ labels,
                                                          const int32_t* __restrict__ idx, int64_t row0, int B, int C,
                                                          float* __restrict__ dZ, double* __restrict__ acc,
-                                                         int32_t* __restrict__ preds, const StepState* __restrict__ st) {
+                                                         int32_t* __restrict__ preds, const StepState* __restrict__ st,
+                                                         int64_t n_rows) {
     __shared__ double lsum[4];
     if (st) row0 = st->row0;
     __shared__ int csum[4];
@@ -935,7 +945,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     int mycorrect = 0;
     for (int r = t; r < B; r += 256) {
         const float* z = Z + (size_t)r * C;
-        const int y = labels[idx ? idx[row0 + r] : row0 + r];
+        const int y = labels[gather_row(idx, row0 + r, n_rows)];
         float mx = z[0];
         int am = 0;
         for (int j = 1; j < C; ++j)
@@ -986,9 +996,9 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 }
 
 void launch_softmax_ce(const float* Z, const int32_t* labels, const int32_t* idx, int64_t row0, int B, int C, float* dZ,
-                       double* acc, int32_t* preds, hipStream_t s, const StepState* st) {
+                       double* acc, int32_t* preds, hipStream_t s, const StepState* st, int64_t n_rows) {
     if (B == 0) return;
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, s, Z, labels, idx, row0, B, C, dZ, acc, preds, st);
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, s, Z, labels, idx, row0, B, C, dZ, acc, preds, st, n_rows);
     CMOOP_HIP(hipGetLastError());
 }
 

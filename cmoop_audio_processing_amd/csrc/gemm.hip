@@ -142,9 +142,36 @@ static GeomDev to_dev(const ConvGeom& g) {
     d.zeros = zero_page();
     CMOOP_REQUIRE(g.KH * g.KW <= 64, "kernel window too large");
     CMOOP_REQUIRE(d.cshift >= 4, "implicit GEMM needs C_in a power of two >= 16");
-    CMOOP_REQUIRE((int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31), "input tensor too large for 32-bit indexing");
-    CMOOP_REQUIRE((int64_t)d.M * g.Cout < (1ll << 31), "output tensor too large for 32-bit indexing");
+    igemm_check_range(g);
     return d;
+}
+
+// The buffer descriptors (num_records), the row tables and the per-row voffsets hold BYTE quantities in 32 bits, some
+// of them through signed ints ((int)(elements) * 4): every tensor a GEMM launch addresses must stay below 2^29 elements
+// (2 GiB), the padding bias of the input descriptor included.  Beyond that the range check of the descriptors would
+// silently return zeros, so the launchers refuse instead.
+void igemm_check_range(const ConvGeom& g) {
+    const int64_t lim = 1ll << 29;
+    const int64_t x_bias = ((int64_t)g.pad_t * g.W + g.pad_l) * g.Cin;
+    CMOOP_REQUIRE((int64_t)g.B * g.H * g.W * g.Cin + x_bias < lim,
+                  "input tensor of a conv layer exceeds 2^29 elements (32-bit byte offsets): lower the batch / eval_batch");
+    CMOOP_REQUIRE((int64_t)g.M() * g.Cout < lim,
+                  "output tensor of a conv layer exceeds 2^29 elements (32-bit byte offsets): lower the batch / eval_batch");
+    CMOOP_REQUIRE((int64_t)g.Cout * g.K() < lim, "conv kernel tensor exceeds 2^29 elements");
+}
+
+std::string gemm_kernel_name(int cls, int code) {
+    if (cls == 0) {
+        const int mode = code / 100000000, c = code % 100000000;
+        const int bm = c / 100000, bn = (c / 100) % 1000, bk = c % 100;
+        const int wm = (bm == bn) ? 2 : 4;   // wave layout of each instantiation (launch_igemm_fwd)
+        return "igemm_fwd_kernel<" + std::to_string(bm) + ", " + std::to_string(bn) + ", " + std::to_string(bk) + ", " +
+               std::to_string(wm) + ", " + std::to_string(mode) + ">";
+    }
+    const int mode = code / 1000000, c = code % 1000000;
+    const std::string tile = std::to_string(c / 1000) + ", " + std::to_string(c % 1000);
+    return mode == GEMM_FP32 ? "igemm_wgrad_kernel<" + tile + ">"
+                             : "igemm_wgrad_bf16_kernel<" + tile + ", " + (mode == GEMM_BF16X3 ? "3" : "1") + ">";
 }
 
 // ---------------------------------------------------------------------------
@@ -886,10 +913,56 @@ size_t igemm_splitk_workspace(const ConvGeom& g) {
     return std::max((size_t)sp * M * N, balanced_slab_floats(M, N, g.K(), g.Cin % 32 == 0 ? 32 : 16, bn_big, nullptr));
 }
 
+// tile / split / operand-path choice of a forward-type launch: pure host arithmetic on the geometry (no HIP call), shared
+// by the launcher and by the host-only launch plan the parity-coverage tests read (igemm_fwd_plan)
+struct FwdChoice {
+    int mode, bm, bn, splits, balanced_wgs, flags;
+    bool bk32_tile, use_dma, stats;
+    int code() const { return mode * 100000000 + bm * 100000 + bn * 100 + (bk32_tile ? 32 : 16); }
+};
+static FwdChoice choose_fwd(const ConvGeom& cg, const GemmEpilogue& ep, size_t ws_floats, bool want_stats, bool have_rowtab) {
+    FwdChoice c;
+    const int M = cg.M(), N = cg.Cout, K = cg.K();
+    c.mode = resolve_mode(ep.mode);
+    // bf16 planes always use 32-deep chunks (a chunk may span two taps of a 16-channel layer; the per-thread tap decode
+    // and the k < K guard handle that)
+    const bool bk32 = c.mode != GEMM_FP32 || (cg.Cin % 32 == 0);
+    pick_tile(M, N, K, bk32 ? 32 : 16, ws_floats, &c.bm, &c.bn, &c.splits, &c.balanced_wgs);
+    // fused column statistics only on un-split launches (split-K partials are raw sums; the caller falls back to the
+    // stand-alone reduction there: those are the small 13x5 / 26x10 layers)
+    c.stats = want_stats && c.splits == 1 && !c.balanced_wgs && ep.out_stride == 1 && !ep.accumulate;
+    // many-wave grids of 128x64 tiles run 3-4 % faster with 16-deep K chunks (half the LDS, 4-5 workgroups
+    // per CU instead of 2); single-wave grids prefer the 32-deep chunk (half the barriers)
+    // (measured: 16-deep chunks for the 128x128 tile -- three workgroups per CU -- 124 vs 130 TFLOP/s: not used)
+    // (measured again with the r2 loader: 32-deep chunks on the >= 1024-tile 128x64 grids 119 vs 123 TFLOP/s: 16 stays)
+    c.bk32_tile = c.mode != GEMM_FP32 ||
+                  (bk32 && !(c.bm == 128 && c.bn == 64 && c.splits == 1 && !c.balanced_wgs && (long)cdiv(M, 128) * cdiv(N, 64) >= 1024));
+    // LDS-DMA operand path: needs the chunk-in-one-tap condition of the fast loader and <= 32 taps.  Measured per tile
+    // (isolated, forward / dgrad TFLOP/s, DMA vs register staging): 128x32 (32-column layers @101x40) 101 / 109 vs 90 / 95
+    // -> used; 128x128 130 vs 132, 128x64 @51x20 111 vs 116, 64->128 dgrad 116 vs 123 -> not used (the DMA fill rate per
+    // wave is the limit once a tile needs four or more 1 KiB fills per operand and chunk).
+    static const int dma_env = [] { const char* v = std::getenv("CMOOP_DMA"); return v ? std::atoi(v) : 1; }();
+    c.use_dma = dma_env && c.mode == GEMM_FP32 && (cg.Cin % 32 == 0) && cg.KH * cg.KW <= 32 && c.bk32_tile && c.bm == 128 && c.bn == 32;
+    if (c.use_dma) c.mode = GEMM_FP32_DMA;      // the instantiation's MODE parameter (rocprofv3 prints it)
+    const int bk = c.bk32_tile ? 32 : 16;
+    c.flags = (c.splits > 1 ? GEMM_FLAG_SPLITK : 0) | (c.stats ? GEMM_FLAG_STATS : 0) | (c.balanced_wgs ? GEMM_FLAG_BALANCED : 0) |
+              ((have_rowtab && (cg.Cin % bk) == 0 && cg.KH * cg.KW <= 32) ? GEMM_FLAG_ROWTAB : 0);
+    return c;
+}
+
+int igemm_fwd_plan(const ConvGeom& g, const GemmEpilogue& ep, size_t ws_floats, bool want_stats, bool have_rowtab, int* flags_out) {
+    igemm_check_range(g);
+    CMOOP_REQUIRE(ilog2_exact(g.Cin) >= 4, "implicit GEMM needs C_in a power of two >= 16");
+    const FwdChoice c = choose_fwd(g, ep, ws_floats, want_stats, have_rowtab);
+    if (flags_out) *flags_out = c.flags;
+    return c.code();
+}
+
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& cg, const GemmEpilogue& ep,
                      hipStream_t s, const GemmTiming* tm, float* splitk_ws, size_t splitk_ws_floats, int* stats_blocks,
-                     const void* rowtab_v, int tab_rows) {
+                     const void* rowtab_v, int tab_rows, int* flags_out) {
     if (stats_blocks) *stats_blocks = 0;
+    if (flags_out) *flags_out = 0;
     const uint2* rowtab = static_cast<const uint2*>(rowtab_v);
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
@@ -898,35 +971,20 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     e.accumulate = ep.accumulate; e.out_stride = ep.out_stride; e.OHf = ep.OHf; e.OWf = ep.OWf;
     e.dropout = ep.dropout; e.drop_prefix = ep.drop_prefix; e.drop_thr = ep.drop_thr; e.drop_scale = ep.drop_scale;
     if (e.out_stride > 1)
-        CMOOP_REQUIRE((int64_t)g.B * e.OHf * e.OWf * g.Cout < (1ll << 31), "scattered output too large");
-    const int mode = resolve_mode(ep.mode);
-    // bf16 planes always use 32-deep chunks (a chunk may span two taps of a 16-channel layer; the per-thread tap decode
-    // and the k < K guard handle that)
-    const bool bk32 = mode != GEMM_FP32 || (g.Cin % 32 == 0);
-    int bm, bn, splits, balanced_wgs;
-    pick_tile(g.M, g.Cout, g.K, bk32 ? 32 : 16, splitk_ws ? splitk_ws_floats : 0, &bm, &bn, &splits, &balanced_wgs);
+        CMOOP_REQUIRE((int64_t)g.B * e.OHf * e.OWf * g.Cout < (1ll << 29), "scattered output too large");
+    const FwdChoice ch = choose_fwd(cg, ep, splitk_ws ? splitk_ws_floats : 0, ep.stats != nullptr && stats_blocks != nullptr, rowtab != nullptr);
+    const int mode = ch.mode == GEMM_FP32_DMA ? (int)GEMM_FP32 : ch.mode;
+    const int bm = ch.bm, bn = ch.bn, splits = ch.splits, balanced_wgs = ch.balanced_wgs;
+    const bool bk32_tile = ch.bk32_tile, use_dma = ch.use_dma;
     e.bal_L = 0; e.bal_segmax = 0;
-    // fused column statistics only on un-split launches (split-K partials are raw sums; the caller falls back to the
-    // stand-alone reduction there: those are the small 13x5 / 26x10 layers)
-    e.stats = (ep.stats && stats_blocks && splits == 1 && !balanced_wgs && ep.out_stride == 1 && !ep.accumulate) ? ep.stats : nullptr;
+    e.stats = ch.stats ? ep.stats : nullptr;
     if (e.stats) *stats_blocks = cdiv(g.M, bm);
-    // many-wave grids of 128x64 tiles run 3-4 % faster with 16-deep K chunks (half the LDS, 4-5 workgroups
-    // per CU instead of 2); single-wave grids prefer the 32-deep chunk (half the barriers)
-    // (measured: 16-deep chunks for the 128x128 tile -- three workgroups per CU -- 124 vs 130 TFLOP/s: not used)
-    // (measured again with the r2 loader: 32-deep chunks on the >= 1024-tile 128x64 grids 119 vs 123 TFLOP/s: 16 stays)
-    const bool bk32_tile = mode != GEMM_FP32 ||
-                           (bk32 && !(bm == 128 && bn == 64 && splits == 1 && !balanced_wgs && (long)cdiv(g.M, 128) * cdiv(g.Cout, 64) >= 1024));
-    // LDS-DMA operand path: needs the chunk-in-one-tap condition of the fast loader and <= 32 taps.  Measured per tile
-    // (isolated, forward / dgrad TFLOP/s, DMA vs register staging): 128x32 (32-column layers @101x40) 101 / 109 vs 90 / 95
-    // -> used; 128x128 130 vs 132, 128x64 @51x20 111 vs 116, 64->128 dgrad 116 vs 123 -> not used (the DMA fill rate per
-    // wave is the limit once a tile needs four or more 1 KiB fills per operand and chunk).
-    static const int dma_env = [] { const char* v = std::getenv("CMOOP_DMA"); return v ? std::atoi(v) : 1; }();
-    const bool use_dma = dma_env && mode == GEMM_FP32 && (g.Cin % 32 == 0) && g.KH * g.KW <= 32;
+    if (flags_out) *flags_out = ch.flags;
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \
     do {                                                                                      \
         if (mode == GEMM_BF16X3) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16X3>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);   \
         else if (mode == GEMM_BF16) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);  \
-        else if (bk32_tile && use_dma && BM_ == 128 && BN_ == 32) launch_fwd_t<BM_, 32, 32, WM_, GEMM_FP32_DMA>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);   \
+        else if (use_dma && BM_ == 128 && BN_ == 32) launch_fwd_t<BM_, 32, 32, WM_, GEMM_FP32_DMA>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);   \
         else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);   \
         else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, 0, rowtab, tab_rows);        \
     } while (0)
@@ -942,7 +1000,7 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
         else CMOOP_FWD(64, 16, 4);
     }
 #undef CMOOP_FWD
-    return mode * 100000000 + bm * 100000 + bn * 100 + (bk32_tile ? 32 : 16);
+    return ch.code();
 }
 
 // ---------------------------------------------------------------------------
@@ -1418,8 +1476,22 @@ int wgrad_slices(const ConvGeom& g) {
     return S;
 }
 
+// instantiation code + flags of the weight-gradient launch for this geometry with S row slices (host arithmetic only)
+int igemm_wgrad_plan(const ConvGeom& g, int S, int mode_req, bool have_rowtab, int* flags_out) {
+    igemm_check_range(g);
+    const int N = g.Cout, M = g.M();
+    const int bco = wgrad_bco(N), bki = wgrad_bki(M, N, g.K());
+    int mode = (N % 4 == 0) ? resolve_mode(mode_req) : (int)GEMM_FP32;
+    if (mode == GEMM_BF16X3 && bco < 128) mode = GEMM_FP32;
+    const bool rt = have_rowtab && g.KH * g.KW <= 32;
+    if (flags_out) *flags_out = ((rt && mode == GEMM_FP32 && (N & 3) == 0) ? GEMM_FLAG_ROWTAB : 0) | (S > 1 ? GEMM_FLAG_SLABS : 0);
+    return mode * 1000000 + bco * 1000 + bki;
+}
+
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s,
-                       const GemmTiming* tm, float* Pbias, size_t slab_stride, int mode_req, const void* rowtab, int tab_rows) {
+                       const GemmTiming* tm, float* Pbias, size_t slab_stride, int mode_req, const void* rowtab, int tab_rows,
+                       int* flags_out) {
+    if (flags_out) *flags_out = 0;
     GeomDev g = to_dev(cg);
     if (g.M == 0) return 0;
     const size_t stride = slab_stride ? slab_stride : (size_t)g.Cout * g.K;
@@ -1442,6 +1514,7 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     }
     // the row table must cover every row a chunk can touch (rows are consumed 32 at a time)
     const uint2* rt = (rowtab && tab_rows >= cdiv(g.M, 32) * 32 && g.KH * g.KW <= 32) ? static_cast<const uint2*>(rowtab) : nullptr;
+    if (flags_out) *flags_out = ((rt && mode == GEMM_FP32 && (g.Cout & 3) == 0) ? GEMM_FLAG_ROWTAB : 0) | (S > 1 ? GEMM_FLAG_SLABS : 0);
 #define CMOOP_WGK(KERNEL)                                                                                       \
     do {                                                                                                       \
         if (tm && tm->start && tm->ext) {                                                                      \

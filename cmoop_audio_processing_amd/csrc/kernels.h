@@ -3,6 +3,7 @@
 // [C_out][kh][kw][C_in] layout (K = kh*kw*C_in contiguous) -- see genes.py.
 #pragma once
 #include "common.h"
+#include <string>
 
 namespace cmoop {
 
@@ -55,11 +56,22 @@ struct GemmTiming {
 // stats_blocks (with e.stats): receives the number of M-tile partials written, 0 when the launch was split-K (no fused statistics)
 // rowtab / tab_rows (optional): the row table of THIS geometry (launch_build_rowtab), covering at least every 128-row tile
 // the launch touches: the kernel then reads each row's offset / padding mask instead of deriving them
+// flags_out (optional): GEMM_FLAG_* of the path the launch took (parity-coverage bookkeeping)
+enum GemmFlags { GEMM_FLAG_SPLITK = 1, GEMM_FLAG_STATS = 2, GEMM_FLAG_ROWTAB = 4, GEMM_FLAG_BALANCED = 8, GEMM_FLAG_SLABS = 16 };
 int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& g,
                      const GemmEpilogue& e, hipStream_t s, const GemmTiming* tm = nullptr,
                      float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, int* stats_blocks = nullptr,
-                     const void* rowtab = nullptr, int tab_rows = 0);
+                     const void* rowtab = nullptr, int tab_rows = 0, int* flags_out = nullptr);
 size_t igemm_splitk_workspace(const ConvGeom& g);
+// host-only twins of the two launchers' choices (no HIP call): the instantiation code and GemmFlags a launch of this
+// geometry takes -- ws_floats: split-K workspace the caller would pass (0: none); S: wgrad row slices (wgrad_slices)
+int igemm_fwd_plan(const ConvGeom& g, const GemmEpilogue& e, size_t ws_floats, bool want_stats, bool have_rowtab, int* flags_out);
+int igemm_wgrad_plan(const ConvGeom& g, int S, int mode, bool have_rowtab, int* flags_out);
+// throws when a tensor of this geometry is beyond the kernels' 32-bit BYTE offsets (buffer descriptors, row tables):
+// B*H*W*Cin (+ padding bias) and M*Cout must stay below 2^29 elements
+void igemm_check_range(const ConvGeom& g);
+// kernel instantiation name as rocprofv3 prints it; cls 0: launch_igemm_fwd's return code, 1: launch_igemm_wgrad's
+std::string gemm_kernel_name(int cls, int code);
 
 // dWt[n][k] = sum_m dY[m][n] * im2col(X)[m][k], split over S row-slices into P[S][N][K].
 int wgrad_slices(const ConvGeom& g);
@@ -72,7 +84,7 @@ int wgrad_slices(const ConvGeom& g);
 // divisions / bounds arithmetic.  A table built for the full batch serves every smaller batch of the same layer.
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& g, int S, hipStream_t s,
                        const GemmTiming* tm = nullptr, float* Pbias = nullptr, size_t slab_stride = 0,
-                       int mode = GEMM_DEFAULT, const void* rowtab = nullptr, int tab_rows = 0);
+                       int mode = GEMM_DEFAULT, const void* rowtab = nullptr, int tab_rows = 0, int* flags_out = nullptr);
 int rowtab_rows(const ConvGeom& g);                                           // entries (8 bytes each) the table needs
 void launch_build_rowtab(const ConvGeom& g, void* tab, hipStream_t s);        // needs KH*KW <= 32
 // out[i] = sum_s P[s][i]  (fixed order -> deterministic)
@@ -122,12 +134,15 @@ void launch_dense_wgrad(const float* X, const float* dY, float* dW, float* dB, i
 // batch rows, fusing Keras' shuffle+batch gather (nsga_penalty.py:383) into the load.
 // ---------------------------------------------------------------------------
 // st (optional): the batch's first row comes from st->row0 instead of row0
+// n_rows (optional, > 0): rows the resident tensor holds -- a gathered row index is clamped into [0, n_rows) so that a
+// corrupt idx can never address outside X (the only producer of idx is the device permutation; this is a fault fence)
 void launch_conv1_fwd(const float* X, const int32_t* idx, int64_t row0, const float* Wt, const float* bias,
-                      float* Y, int B, int H, int W, int Cout, int KS, int relu, hipStream_t s, const StepState* st = nullptr);
+                      float* Y, int B, int H, int W, int Cout, int KS, int relu, hipStream_t s, const StepState* st = nullptr,
+                      int64_t n_rows = 0);
 int conv1_wgrad_blocks(int B, int H, int W);
 // P[blk][Cout*(KS*KS) + Cout]: per-block partial kernel grads then bias grads
 void launch_conv1_wgrad(const float* X, const int32_t* idx, int64_t row0, const float* dY, float* P,
-                        int B, int H, int W, int Cout, int KS, hipStream_t s, const StepState* st = nullptr);
+                        int B, int H, int W, int Cout, int KS, hipStream_t s, const StepState* st = nullptr, int64_t n_rows = 0);
 
 // ---------------------------------------------------------------------------
 // Per-channel reductions over the M rows of an [M][C] tensor (C % 4 == 0).
@@ -182,7 +197,7 @@ void launch_gap_bwd(const float* dY, const float* X, float* dX, int B, int HW, i
 // softmax + clipped sparse CE (+ gradient wrt logits when dZ != null); adds into
 // acc[0] (double: sum of per-sample losses) and acc[1] (as int64: correct); writes preds when non-null.
 void launch_softmax_ce(const float* Z, const int32_t* labels, const int32_t* idx, int64_t row0, int B, int C,
-                       float* dZ, double* acc, int32_t* preds, hipStream_t s, const StepState* st = nullptr);
+                       float* dZ, double* acc, int32_t* preds, hipStream_t s, const StepState* st = nullptr, int64_t n_rows = 0);
 // st != null: alpha = alpha_table[st->iter] (host-precomputed per iteration: the Keras step size in double, rounded once)
 void launch_adam(float* w, const float* g, float* m, float* v, int64_t n, float alpha, float c1, float c2,
                  float eps, hipStream_t s, const StepState* st = nullptr, const float* alpha_table = nullptr);

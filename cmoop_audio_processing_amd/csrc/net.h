@@ -8,6 +8,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -37,13 +38,17 @@ struct ProfileEntry { double ms = 0, flops = 0; long long launches = 0; };
 struct ProfileTotals {   // keyed by kernel instantiation name, e.g. "igemm_fwd_kernel<128,32>"
     std::mutex mu;
     std::map<std::string, ProfileEntry> by_kernel;
-    void reset() { std::lock_guard<std::mutex> l(mu); by_kernel.clear(); }
+    // launch-path variants seen: name + "+sk" (split-K slabs + combine) / "+stats" (BatchNorm statistics epilogue) /
+    // "+tab" (row-table operand loader) / "+bal" / "+slabs" (several row slices) -- what the parity-coverage test compares
+    std::set<std::string> variants;
+    void reset() { std::lock_guard<std::mutex> l(mu); by_kernel.clear(); variants.clear(); }
 };
+std::string gemm_variant_name(int cls, int code, int flags);
 ProfileTotals& profile_totals();
 
 struct GemmHook {   // brackets every MFMA GEMM launch (HIP-event sampling)
     virtual const GemmTiming* begin(int cls, double flops) = 0;   // null: do not time this launch
-    virtual void end(int code) = 0;
+    virtual void end(int code, int flags) = 0;   // code: instantiation (gemm_kernel_name), flags: GemmFlags of the path taken
     virtual ~GemmHook() {}
 };
 // wgrad_ws holds wgrad_ws_floats floats; the slice count is clamped to what fits (never written past)
@@ -110,7 +115,7 @@ struct Op {
 class Net : public GemmHook {
   public:
     const GemmTiming* begin(int cls, double flops) override;
-    void end(int code) override;
+    void end(int code, int flags) override;
     Net(const int32_t gene[6], const NetConfig& cfg, int T, int F, uint32_t seed, hipStream_t stream);
     ~Net();
     Net(const Net&) = delete;
@@ -122,13 +127,22 @@ class Net : public GemmHook {
     void get_grads(float* host);
     void snapshot_params();   // device copy (restore_best_weights)
     void restore_snapshot();
+    // full training state: parameters (BatchNorm moving statistics included), Adam m / v, optimizer.iterations and the
+    // global step that keys the dropout masks -- what a checker needs to re-synchronise with this net at an epoch boundary
+    void get_state(float* params, float* m, float* v, long long* iterations, long long* steps);
+    void set_state(const float* params, const float* m, const float* v, long long iterations, long long steps);
+    // rows of the resident tensor the next train steps gather from (0: unknown, no clamp)
+    void set_gather_rows(int64_t n) { gather_rows_ = n; }
+    // ONE epoch of Model.fit on the production path (device permutation of (seed, epoch) when cfg.shuffle, device
+    // StepState steps, last partial batch kept); idx_scratch: n_train int32 on the device
+    void run_epoch(const float* X, const int32_t* y, int64_t n_train, int epoch, int32_t* idx_scratch);
 
     // fwd + bwd + Adam on rows idx[row0 .. row0+B) (idx may be null -> rows row0..)
     void train_step(const float* X, const int32_t* y, const int32_t* idx, int64_t row0, int B);
     // The fit loop's form of the same step: the batch position, dropout counter and Adam iteration live in a device
     // StepState (kernels.h), so a full-batch step has no per-step host arguments; with CMOOP_GRAPH=1 it is captured ONCE
     // as a hipGraph and replayed (opt-in: measured no faster than eager launches, see begin_fit).
-    void begin_fit(int64_t total_steps);      // uploads Adam's per-iteration step sizes, zeroes the state
+    void begin_fit(int64_t total_steps);      // uploads Adam's per-iteration step sizes, sets the device state to (0, step, iterations)
     void begin_epoch();                       // state.row0 = 0
     void train_step_stateful(const float* X, const int32_t* y, const int32_t* idx, int B);
     // inference over n rows of (X, y); returns sum of per-sample losses and #correct, fills preds (device, may be null)
@@ -136,6 +150,10 @@ class Net : public GemmHook {
     void read_train_metrics(double* loss_sum, long long* correct, bool reset);
     void drain_profile();
     hipStream_t stream() const { return stream_; }
+    uint32_t seed() const { return seed_; }
+    const NetConfig& config() const { return cfg_; }
+    int feature_T() const { return T_; }
+    int feature_F() const { return F_; }
     long long steps_done() const { return step_; }
 
   private:
@@ -161,7 +179,7 @@ class Net : public GemmHook {
     float *wgrad_ws_ = nullptr, *wd_ws_ = nullptr, *red_ws_ = nullptr, *splitk_ws_ = nullptr;
     StepState* st_dev_ = nullptr;       // device step state (train_step_stateful)
     float* alpha_tab_ = nullptr;        // Adam step size per iteration
-    int64_t alpha_tab_n_ = 0, host_row0_ = 0;
+    int64_t alpha_tab_n_ = 0, host_row0_ = 0, gather_rows_ = 0;
     hipGraphExec_t graph_exec_ = nullptr;   // the captured full-batch train step
     bool graph_ok_ = true;
     FlipEntry* flip_table_ = nullptr;   // device table of the conv layers whose dgrad needs flip-transposed weights
@@ -175,7 +193,7 @@ class Net : public GemmHook {
     long long step_ = 0, iterations_ = 0;
     bool profiling_now_ = false, hook_live_ = false;
     int fused_stats_blocks_ = 0;   // > 0: the conv just launched left this many BatchNorm statistic partials in red_ws_
-    struct EvPair { GemmTiming t; double flops; int cls, code; };
+    struct EvPair { GemmTiming t; double flops; int cls, code, flags; };
     std::vector<EvPair> ev_pool_;
     size_t ev_used_ = 0;
 };
@@ -186,8 +204,18 @@ struct EvalResult {
     int evaluated = 0;   // 1 when THIS call trained the candidate (always, unless a pull callback handed it to another rank)
 };
 
+// per-epoch record of a fit (tests: the early-stopping decisions are checked against the validation-loss history)
+struct FitHistory {
+    std::vector<double> val_loss, val_acc;
+    int best_epoch = -1;
+};
+// Model.fit + EarlyStopping + the read-outs on an EXISTING net (the body of run_candidate); seed keys the epoch shuffle
+EvalResult fit_and_read_out(Net& net, const NetConfig& cfg, const Dataset& ds, uint32_t seed, FitHistory* hist = nullptr);
 // train-to-early-stop + readouts for one candidate (evaluate_individual, nsga_penalty.py:368-395)
 EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Dataset& ds, uint32_t seed, hipStream_t stream);
+// host-only: every implicit-GEMM conv geometry of a candidate at batch B (plan walk without device memory); throws
+// through igemm_check_range when a layer is beyond the kernels' 32-bit byte offsets
+void check_plan_ranges(const int32_t gene[6], int variant, int T, int F, int B);
 // the population loop (compute_objectives_and_constraints, nsga_penalty.py:418-442): n_slots
 // candidates in flight on their own HIP streams, longest-first
 // pull (optional): called by the worker threads (concurrently) for the next candidate index, < 0 = queue exhausted --

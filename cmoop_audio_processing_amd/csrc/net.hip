@@ -180,6 +180,7 @@ Net::Net(const int32_t gene[6], const NetConfig& cfg, int T, int F, uint32_t see
     CMOOP_REQUIRE(T >= 1 && F >= 1, "bad feature shape");
     std::memcpy(gene_, gene, sizeof(gene_));
     Bmax_ = std::max(cfg.batch, cfg.eval_batch);
+    check_plan_ranges(gene, cfg.variant, T, F, Bmax_);   // fail at creation, not in the middle of a fit
     build_plan();
 }
 
@@ -234,7 +235,10 @@ void Net::build_plan() {
     };
     auto add_pool = [&](int in, int mask_y_pos) {
         Op op; op.kind = OP_POOL; op.in = in; op.mask_y_pos = mask_y_pos;
-        if (!ops_.empty() && ops_.back().kind == OP_BN && ops_.back().out == in && !mask_y_pos) {
+        // CMOOP_BN_POOL_UNFUSED=1 (read per net: tests A/B the fused kernels against scale_shift + maxpool, bit for bit)
+        const char* unf = std::getenv("CMOOP_BN_POOL_UNFUSED");
+        const bool fuse_ok = !(unf && unf[0] == '1');
+        if (fuse_ok && !ops_.empty() && ops_.back().kind == OP_BN && ops_.back().out == in && !mask_y_pos) {
             ops_.back().fuse_pool = 1;      // BN-apply (+ReLU) + pool in one pass; the BN output is never written
             op.fused_into_bn = 1;
             acts_[in].virt = true;
@@ -472,11 +476,22 @@ const GemmTiming* Net::begin(int cls, double flops) {
     ev_pool_[ev_used_].cls = cls;
     return &ev_pool_[ev_used_].t;
 }
-void Net::end(int code) {
+void Net::end(int code, int flags) {
     if (!hook_live_) return;
     ev_pool_[ev_used_].code = code;
+    ev_pool_[ev_used_].flags = flags;
     ++ev_used_;
     hook_live_ = false;
+}
+
+std::string gemm_variant_name(int cls, int code, int flags) {
+    std::string v = gemm_kernel_name(cls, code);
+    if (flags & GEMM_FLAG_SPLITK) v += "+sk";
+    if (flags & GEMM_FLAG_BALANCED) v += "+bal";
+    if (flags & GEMM_FLAG_STATS) v += "+stats";
+    if (flags & GEMM_FLAG_ROWTAB) v += "+tab";
+    if (flags & GEMM_FLAG_SLABS) v += "+slabs";
+    return v;
 }
 
 // dW[N][K] and db[N] of a conv / dense layer: MFMA split over row slices, then a fixed-order slice sum
@@ -496,8 +511,9 @@ void conv_backward_weights(const float* X, const float* dY, float* dW, float* dB
     float* Pk = in_place ? dW : wgrad_ws;
     float* Pbias = in_place ? dB : wgrad_ws + NK;
     const GemmTiming* tm = hook ? hook->begin(1, 2.0 * M * (double)N * K) : nullptr;
-    const int code = launch_igemm_wgrad(X, dY, Pk, g, S, s, tm, Pbias, in_place ? NK : stride, mode, rowtab, tab_rows);
-    if (hook) hook->end(code);
+    int flags = 0;
+    const int code = launch_igemm_wgrad(X, dY, Pk, g, S, s, tm, Pbias, in_place ? NK : stride, mode, rowtab, tab_rows, &flags);
+    if (hook) hook->end(code, flags);
     if (defer) {
         CMOOP_REQUIRE(dB == dW + NK, "deferred slice sum needs the bias gradient directly after the kernel gradient");
         defer->n = (int64_t)stride;
@@ -540,8 +556,9 @@ void conv_backward_data(const float* dY, const float* W, float* dX, const ConvGe
     e.mask = mask;
     e.mask_scale = mask_scale;
     const GemmTiming* tm = hook ? hook->begin(0, 2.0 * gd.M() * (double)gd.Cout * gd.K()) : nullptr;
-    const int code = launch_igemm_fwd(dY, wd_ws, dX, gd, e, s, tm, sk_ws, sk_floats, nullptr, rowtab_d, rowtab_d_rows);
-    if (hook) hook->end(code);
+    int flags = 0;
+    const int code = launch_igemm_fwd(dY, wd_ws, dX, gd, e, s, tm, sk_ws, sk_floats, nullptr, rowtab_d, rowtab_d_rows, &flags);
+    if (hook) hook->end(code, flags);
 }
 
 ConvGeom dgrad_geometry(const ConvGeom& g) {
@@ -559,7 +576,9 @@ ConvGeom dgrad_geometry(const ConvGeom& g) {
 void Net::run_gemm(int cls, const float* X, const float* Wt, float* Y, const ConvGeom& g, const GemmEpilogue& e, int* stats_blocks,
                    const void* rowtab, int tab_rows) {
     const GemmTiming* tm = begin(cls, 2.0 * g.M() * (double)g.Cout * g.K());
-    end(launch_igemm_fwd(X, Wt, Y, g, e, stream_, tm, splitk_ws_, splitk_ws_floats_, stats_blocks, rowtab, tab_rows));
+    int flags = 0;
+    const int code = launch_igemm_fwd(X, Wt, Y, g, e, stream_, tm, splitk_ws_, splitk_ws_floats_, stats_blocks, rowtab, tab_rows, &flags);
+    end(code, flags);
 }
 
 void Net::drain_profile() {
@@ -570,20 +589,8 @@ void Net::drain_profile() {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev_pool_[i].t.start, ev_pool_[i].t.stop) == hipSuccess) {
             // instantiation names as rocprofv3 prints them (codes: launch_igemm_fwd / launch_igemm_wgrad)
-            const int code = ev_pool_[i].code;
-            std::string name;
-            if (ev_pool_[i].cls == 0) {
-                const int mode = code / 100000000, c = code % 100000000;
-                const int bm = c / 100000, bn = (c / 100) % 1000, bk = c % 100;
-                const int wm = (bm == bn) ? 2 : 4;   // wave layout of each instantiation (gemm.hip)
-                name = "igemm_fwd_kernel<" + std::to_string(bm) + ", " + std::to_string(bn) + ", " + std::to_string(bk) + ", " +
-                       std::to_string(wm) + ", " + std::to_string(mode) + ">";
-            } else {
-                const int mode = code / 1000000, c = code % 1000000;
-                const std::string tile = std::to_string(c / 1000) + ", " + std::to_string(c % 1000);
-                name = mode == GEMM_FP32 ? "igemm_wgrad_kernel<" + tile + ">"
-                                         : "igemm_wgrad_bf16_kernel<" + tile + ", " + (mode == GEMM_BF16X3 ? "3" : "1") + ">";
-            }
+            const std::string name = gemm_kernel_name(ev_pool_[i].cls, ev_pool_[i].code);
+            t.variants.insert(gemm_variant_name(ev_pool_[i].cls, ev_pool_[i].code, ev_pool_[i].flags));
             ProfileEntry& e = t.by_kernel[name];
             e.ms += ms;
             e.flops += ev_pool_[i].flops;
@@ -601,7 +608,7 @@ void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool 
         switch (op.kind) {
         case OP_CONV1:
             launch_conv1_fwd(X, idx, row0, params_ + op.w_off, params_ + op.b_off, acts_[op.out].data, B, T_, F_, op.Cout,
-                             op.KS, op.relu, stream_, st);
+                             op.KS, op.relu, stream_, st, train ? gather_rows_ : 0);
             break;
         case OP_CONV: {
             GemmEpilogue e;
@@ -736,7 +743,8 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B, cons
             break;
         }
         case OP_CONV1: {
-            launch_conv1_wgrad(X, idx, row0, acts_[op.out].grad, wgrad_ws_ + op.slab_off, B, T_, F_, op.Cout, op.KS, stream_, st);
+            launch_conv1_wgrad(X, idx, row0, acts_[op.out].grad, wgrad_ws_ + op.slab_off, B, T_, F_, op.Cout, op.KS, stream_, st,
+                               gather_rows_);
             AdamSeg sg;
             sg.off = op.w_off;
             sg.n = sg.stride = (int64_t)op.Cout * (op.KS * op.KS + 1);
@@ -755,7 +763,8 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B, cons
 // st != null: batch position / dropout counter / Adam iteration come from the device state, which the step advances
 void Net::step_body(const float* X, const int32_t* y, const int32_t* idx, int64_t row0, int B, const StepState* st) {
     forward(X, idx, row0, B, true, st);
-    launch_softmax_ce(acts_[logits_].data, y, idx, row0, B, cfg_.classes, acts_[logits_].grad, acc_train_, nullptr, stream_, st);
+    launch_softmax_ce(acts_[logits_].data, y, idx, row0, B, cfg_.classes, acts_[logits_].grad, acc_train_, nullptr, stream_, st,
+                      gather_rows_);
     backward(X, idx, row0, B, st);
     const double t = (double)(iterations_ + 1);
     const double b1 = cfg_.beta1, b2 = cfg_.beta2;
@@ -800,8 +809,9 @@ void Net::train_step(const float* X, const int32_t* y, const int32_t* idx, int64
 }
 
 void Net::begin_fit(int64_t total_steps) {
-    CMOOP_REQUIRE(step_ == 0 && iterations_ == 0, "begin_fit on a net that has already trained");
-    if (total_steps < 1 || total_steps > (1ll << 24)) { graph_ok_ = false; return; }   // explicit-argument steps beyond 16 M iterations
+    // total_steps counts from optimizer.iterations == 0; a net that has already trained (session API: state loaded with
+    // set_state, or earlier epochs) continues from its own counters
+    if (total_steps < 1 || total_steps > (1ll << 24)) { graph_ok_ = false; st_dev_ = nullptr; return; }   // explicit-argument steps beyond 16 M iterations
     std::vector<float> tab(total_steps);
     const double b1 = cfg_.beta1, b2 = cfg_.beta2;
     for (int64_t i = 0; i < total_steps; ++i) {
@@ -810,10 +820,11 @@ void Net::begin_fit(int64_t total_steps) {
     }
     alpha_tab_ = dalloc(total_steps);
     alpha_tab_n_ = total_steps;
-    st_dev_ = reinterpret_cast<StepState*>(dalloc(8));
+    if (!st_dev_) st_dev_ = reinterpret_cast<StepState*>(dalloc(8));
     CMOOP_HIP(hipMemcpyAsync(alpha_tab_, tab.data(), total_steps * 4, hipMemcpyHostToDevice, stream_));
-    CMOOP_HIP(hipMemsetAsync(st_dev_, 0, sizeof(StepState), stream_));
-    CMOOP_HIP(hipStreamSynchronize(stream_));     // tab is a local
+    const StepState st0{0, (unsigned)step_, (unsigned)iterations_};
+    CMOOP_HIP(hipMemcpyAsync(st_dev_, &st0, sizeof(StepState), hipMemcpyHostToDevice, stream_));
+    CMOOP_HIP(hipStreamSynchronize(stream_));     // tab and st0 are locals
     // hipGraph replay of the captured step is OPT-IN (CMOOP_GRAPH=1).  Measured: a lone 16-filter candidate runs 2 591
     // steps/s replayed vs 2 625 launched eagerly (its stream is kept busy either way: ~50 kernels of ~8 us per step,
     // the host launches faster than that), and the pop-40 bench is 1.5 % slower replayed (2 089 vs 2 121 evals/h).
@@ -867,6 +878,60 @@ void Net::train_step_stateful(const float* X, const int32_t* y, const int32_t* i
     ++iterations_;
     ++step_;
     profiling_now_ = false;
+}
+
+void Net::get_state(float* params, float* m, float* v, long long* iterations, long long* steps) {
+    if (params) CMOOP_HIP(hipMemcpyAsync(params, params_, n_params_ * 4, hipMemcpyDeviceToHost, stream_));
+    if (m) CMOOP_HIP(hipMemcpyAsync(m, adam_m_, n_params_ * 4, hipMemcpyDeviceToHost, stream_));
+    if (v) CMOOP_HIP(hipMemcpyAsync(v, adam_v_, n_params_ * 4, hipMemcpyDeviceToHost, stream_));
+    CMOOP_HIP(hipStreamSynchronize(stream_));
+    if (iterations) *iterations = iterations_;
+    if (steps) *steps = step_;
+}
+
+void Net::set_state(const float* params, const float* m, const float* v, long long iterations, long long steps) {
+    CMOOP_REQUIRE(iterations >= 0 && steps >= 0 && iterations < (1ll << 31) && steps < (1ll << 31), "set_state: counters out of range");
+    if (params) CMOOP_HIP(hipMemcpyAsync(params_, params, n_params_ * 4, hipMemcpyHostToDevice, stream_));
+    if (m) CMOOP_HIP(hipMemcpyAsync(adam_m_, m, n_params_ * 4, hipMemcpyHostToDevice, stream_));
+    if (v) CMOOP_HIP(hipMemcpyAsync(adam_v_, v, n_params_ * 4, hipMemcpyHostToDevice, stream_));
+    iterations_ = iterations;
+    step_ = steps;
+    if (st_dev_) {
+        const StepState st0{0, (unsigned)step_, (unsigned)iterations_};
+        CMOOP_HIP(hipMemcpyAsync(st_dev_, &st0, sizeof(StepState), hipMemcpyHostToDevice, stream_));
+    }
+    CMOOP_HIP(hipStreamSynchronize(stream_));
+    if (graph_exec_) { hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+}
+
+void Net::run_epoch(const float* X, const int32_t* y, int64_t n_train, int epoch, int32_t* idx_scratch) {
+    CMOOP_REQUIRE(n_train >= 1 && n_train < (1ll << 31) && epoch >= 0, "run_epoch: bad arguments");
+    const int64_t spe = (n_train + cfg_.batch - 1) / cfg_.batch;
+    // the device StepState / step-size table of the fit loop, (re)built when this epoch runs past what is there
+    if (!st_dev_ || iterations_ + spe > alpha_tab_n_)
+        begin_fit(std::max<int64_t>((int64_t)std::max(cfg_.epochs, 1) * spe, iterations_ + spe));
+    const int32_t* idx = nullptr;
+    if (cfg_.shuffle) {
+        CMOOP_REQUIRE(idx_scratch != nullptr, "run_epoch: shuffle needs an index buffer");
+        if (n_train <= EPOCH_PERMUTATION_DEVICE_MAX) {
+            launch_epoch_permutation(seed_, (uint32_t)epoch, n_train, idx_scratch, stream_);
+        } else {
+            std::vector<int32_t> h(n_train);
+            epoch_permutation(seed_, (uint32_t)epoch, n_train, h.data());
+            CMOOP_HIP(hipMemcpyAsync(idx_scratch, h.data(), n_train * 4, hipMemcpyHostToDevice, stream_));
+            CMOOP_HIP(hipStreamSynchronize(stream_));
+        }
+        idx = idx_scratch;
+    }
+    set_gather_rows(n_train);
+    if (st_dev_) {   // explicit-argument steps (session API) do not advance the device state: start the epoch from the host's counters
+        const StepState st0{0, (unsigned)step_, (unsigned)iterations_};
+        CMOOP_HIP(hipMemcpyAsync(st_dev_, &st0, sizeof(StepState), hipMemcpyHostToDevice, stream_));
+        CMOOP_HIP(hipStreamSynchronize(stream_));
+    }
+    begin_epoch();
+    for (int64_t s = 0; s < n_train; s += cfg_.batch)
+        train_step_stateful(X, y, idx, (int)std::min<int64_t>(cfg_.batch, n_train - s));
 }
 
 void Net::evaluate(const float* X, const int32_t* y, int64_t n, double* loss_sum, long long* correct, int32_t* preds) {
@@ -925,11 +990,11 @@ double fpr_from_confusion(const int64_t* cm, int C, int variant) {
     return cnt ? sum / cnt : 0.0;
 }
 
-EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Dataset& ds, uint32_t seed, hipStream_t stream) {
+EvalResult fit_and_read_out(Net& net, const NetConfig& cfg, const Dataset& ds, uint32_t seed, FitHistory* hist) {
     const auto t0 = std::chrono::steady_clock::now();
     CMOOP_REQUIRE(ds.n_train >= 1 && ds.n_val >= 1, "empty train or validation split");
     CMOOP_REQUIRE(ds.n_train < (1ll << 31) && ds.n_val < (1ll << 31), "split too large");
-    Net net(gene, cfg, ds.T, ds.F, seed, stream);
+    hipStream_t stream = net.stream();
     EvalResult res;
     res.size_mb = (double)(net.total_params() * 4) / (1024.0 * 1024.0);   // compute_model_size_mb, nsga_penalty.py:337-344
 
@@ -947,6 +1012,7 @@ EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Data
         long long last_corr = 0;
         int wait = 0, best_epoch = -1;
         bool have_best = false, preds_are_final = false;
+        net.set_gather_rows(ds.n_train);
         net.begin_fit((int64_t)cfg.epochs * ((ds.n_train + cfg.batch - 1) / cfg.batch));
         for (int epoch = 0; epoch < cfg.epochs; ++epoch) {
             if (cfg.shuffle && ds.n_train <= EPOCH_PERMUTATION_DEVICE_MAX) {
@@ -969,6 +1035,7 @@ EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Data
             last_corr = corr;
             preds_are_final = true;     // d_preds / last_val_* describe the weights the net holds right now
             res.epochs_run = epoch + 1;
+            if (hist) { hist->val_loss.push_back(last_val_loss); hist->val_acc.push_back(last_val_acc); }
             if (!cfg.early_stop) continue;
             if (cfg.restore_best && !have_best) { net.snapshot_params(); have_best = true; }
             ++wait;
@@ -981,6 +1048,7 @@ EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Data
             }
             if (wait >= cfg.patience && epoch > 0) break;
         }
+        if (hist) hist->best_epoch = best_epoch;
         if (cfg.early_stop && cfg.restore_best && have_best && best_epoch != res.epochs_run - 1) {
             net.restore_snapshot();      // weights of an earlier epoch: the last pass's predictions no longer apply
             preds_are_final = false;
@@ -1005,6 +1073,39 @@ EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Data
     cleanup();
     res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return res;
+}
+
+EvalResult run_candidate(const int32_t gene[6], const NetConfig& cfg, const Dataset& ds, uint32_t seed, hipStream_t stream) {
+    const auto t0 = std::chrono::steady_clock::now();
+    CMOOP_REQUIRE(ds.n_train >= 1 && ds.n_val >= 1, "empty train or validation split");
+    Net net(gene, cfg, ds.T, ds.F, seed, stream);
+    EvalResult res = fit_and_read_out(net, cfg, ds, seed, nullptr);
+    res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return res;
+}
+
+// plan walk without device memory (the conv stack of Net::build_plan): conv geometries of a candidate at batch B
+void check_plan_ranges(const int32_t gene[6], int variant, int T, int F, int B) {
+    validate_gene(gene);
+    const int f = gene[0], k = gene[1], R = gene[3];
+    auto geom = [&](int H, int W, int Cin, int Cout, int KS, int stride) {
+        ConvGeom g;
+        g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.KH = g.KW = KS; g.stride = stride;
+        g.OH = (H + stride - 1) / stride; g.OW = (W + stride - 1) / stride;
+        g.pad_t = std::max((g.OH - 1) * stride + KS - H, 0) / 2;
+        g.pad_l = std::max((g.OW - 1) * stride + KS - W, 0) / 2;
+        return g;
+    };
+    // first conv (C_in = 1, direct kernel): its output feeds the GEMM layers, so the same element bound applies to it
+    CMOOP_REQUIRE((int64_t)B * T * F * f < (1ll << 29), "first-layer output exceeds 2^29 elements (32-bit byte offsets): lower the batch / eval_batch");
+    if (variant == 0) igemm_check_range(geom(T, F, f, f, k, 1));
+    int h = (T + 1) / 2, w = (F + 1) / 2, c = f;
+    for (int r = 0; r < R; ++r) {
+        igemm_check_range(geom(h, w, c, 2 * c, 1, 2));
+        igemm_check_range(geom(h, w, c, 2 * c, k, 1));
+        if (variant == 0) igemm_check_range(geom(h, w, 2 * c, 2 * c, k, 1));
+        h = (h + 1) / 2; w = (w + 1) / 2; c *= 2;
+    }
 }
 
 void eval_population(const NetConfig& cfg, const Dataset& ds, const int32_t* genes, const uint32_t* seeds, int n,

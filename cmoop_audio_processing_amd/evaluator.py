@@ -212,7 +212,7 @@ def queue_plan(costs: Sequence[float], world: int, slots: int) -> Tuple[List[int
 
 
 def queued_map(local_pull_fn: Callable[..., Dict[int, Sequence[float]]], costs: Sequence[float], width: int,
-               key: str, device: str = "cpu", slots: Optional[int] = None) -> np.ndarray:
+               key: str, device: str = "cpu", slots: Optional[int] = None, stats: Optional[Dict] = None) -> np.ndarray:
     """Evaluate items 0..n-1 across the ranks through ONE shared longest-first queue.
 
     ``slots`` (worker threads a rank may run): with it, ``local_pull_fn(pull, workers)`` is called with the number of
@@ -226,9 +226,15 @@ def queued_map(local_pull_fn: Callable[..., Dict[int, Sequence[float]]], costs: 
     This is the cross-rank twin of the in-GPU queue of ``eval_population`` (csrc/net.hip): with early stopping the
     epochs a candidate runs are unknown in advance (7...173 observed), which static LPT buckets cannot balance.
     Without a process group the queue is a local counter.
+
+    ``stats`` (optional dict) receives what makes a multi-GPU run diagnosable: ``store_adds`` / ``store_add_us_mean`` /
+    ``store_add_us_max`` (round trips of the shared counter from this rank), ``dealt_here`` (candidates this rank started
+    from the deterministic deal), ``local_s`` (wall seconds this rank spent evaluating) and ``all_gather_ms``.
     """
     import itertools
     import threading
+    import time as _time
+    add_us: List[float] = []
     n = len(costs)
     dist = _dist()
     multi = dist is not None and dist.get_world_size() > 1
@@ -246,7 +252,9 @@ def queued_map(local_pull_fn: Callable[..., Dict[int, Sequence[float]]], costs: 
             with lock:
                 if head:
                     return head.pop(0)
+            t0 = _time.perf_counter()
             j = int(store.add(key, 1)) - 1 + dealt
+            add_us.append((_time.perf_counter() - t0) * 1e6)
             return order[j] if j < n else -1
     else:
         ctr = itertools.count()
@@ -257,12 +265,19 @@ def queued_map(local_pull_fn: Callable[..., Dict[int, Sequence[float]]], costs: 
                     return head.pop(0)
                 j = next(ctr) + dealt
             return order[j] if j < n else -1
+    n_dealt_here = len(head)
+    t_local = _time.perf_counter()
     if not n:
         mine = {}
     elif workers is None:
         mine = local_pull_fn(pull)
     else:
         mine = local_pull_fn(pull, workers)
+    t_local = _time.perf_counter() - t_local
+    if stats is not None:
+        stats.update(store_adds=len(add_us), store_add_us_mean=float(np.mean(add_us)) if add_us else 0.0,
+                     store_add_us_max=float(np.max(add_us)) if add_us else 0.0, dealt_here=n_dealt_here, local_s=t_local,
+                     all_gather_ms=0.0)
     local = np.full((n, width + 1), np.nan, dtype=np.float64)
     local[:, width] = 0.0
     for i, row in mine.items():
@@ -280,10 +295,13 @@ def queued_map(local_pull_fn: Callable[..., Dict[int, Sequence[float]]], costs: 
     recv = torch.empty((world * max(n, 1), width + 1), dtype=torch.float64, device=device)
     if n == 0:
         send = torch.zeros((1, width + 1), dtype=torch.float64, device=device)
+    t_ag = _time.perf_counter()
     dist.all_gather_into_tensor(recv, send)
     if n == 0:
         return np.zeros((0, width), dtype=np.float64)
-    allr = recv.cpu().numpy().reshape(world, n, width + 1)
+    allr = recv.cpu().numpy().reshape(world, n, width + 1)       # the .cpu() copy waits for the collective
+    if stats is not None:
+        stats["all_gather_ms"] = (_time.perf_counter() - t_ag) * 1e3
     owners = allr[:, :, width]
     if not bool((owners.sum(axis=0) == 1.0).all()):
         raise _lib.CmoopError(f"queued_map: every candidate must be evaluated by exactly one rank, got {owners.sum(axis=0)}")
@@ -313,6 +331,7 @@ class PopulationEvaluator:
         self.last_rank_of: List[int] = []   # which rank trained each candidate of the last generation
         self.last_epochs_run: List[int] = []
         self.last_seconds: List[float] = []
+        self.last_queue_stats: Dict = {}     # multi-GPU diagnostics of the last generation on THIS rank (queued_map's stats)
         torch.cuda.synchronize()
 
     # -- low level ------------------------------------------------------------
@@ -406,9 +425,11 @@ class PopulationEvaluator:
                                                           np.full((len(idx), 1), rank)], axis=1), costs, 6, device="cuda")
         else:                                       # one longest-first queue drained by all ranks (default)
             rank = float(dist.get_rank())
+            self.last_queue_stats = {}
             res = queued_map(lambda pull, workers: {i: np.append(r, rank)
                                                     for i, r in self.evaluate_genes_pull(gl, seeds, pull, workers).items()},
-                             costs, 6, f"{self._queue_prefix}/{self._generation}", device="cuda", slots=self.config.n_slots)
+                             costs, 6, f"{self._queue_prefix}/{self._generation}", device="cuda", slots=self.config.n_slots,
+                             stats=self.last_queue_stats)
         self.last_rank_of = [int(r) for r in res[:, 5]]
         self.evals_done += n
         self.last_epochs_run = [int(e) for e in res[:, 3]]

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CMOOP_ABI_VERSION 2
+#define CMOOP_ABI_VERSION 3
 
 /* topologies hidden behind the reference's build_model(hparams) */
 #define CMOOP_VARIANT_A 0 /* "deep":    nsga_penalty.py:225-334, mobo_penalty.py:128-194 */
@@ -105,6 +105,18 @@ int cmoop_eval_population_pull(const cmoop_config* cfg, const cmoop_dataset* ds,
                                double* size_mb, double* fpr, int32_t* epochs_run, double* val_loss, double* seconds,
                                int32_t* evaluated /* [n], required */);
 
+/* host-only: does every conv layer of this candidate at `batch` rows per launch (pass max(batch, eval_batch)) stay inside
+ * the kernels' 32-bit byte offsets (each activation / kernel tensor below 2^29 elements)?  Non-zero + message if not;
+ * cmoop_net_create and the population calls make the same check before they allocate anything. */
+int cmoop_plan_check(const int32_t gene[6], int32_t variant, int32_t T, int32_t F, int32_t batch);
+
+/* host-only: the launch-path variant (kernel instantiation as rocprofv3 names it + "+sk" / "+stats" / "+tab" / "+slabs",
+ * see cmoop_profile_variant) the TRAINER uses for one conv layer at this batch: op 0 forward (want_stats: the layer
+ * feeds a BatchNorm), 1 dgrad, 2 wgrad.  Pure arithmetic on the shape -- tests enumerate every layer of every gene with
+ * it and require a GPU parity case for each variant. */
+int cmoop_conv_launch_plan(int32_t op, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride,
+                           int32_t want_stats, char* name, int32_t name_cap);
+
 /* host-only: number of row slices the weight-gradient kernel splits a conv/dense layer into (workspace sizing;
  * NOT monotone in B -- tests pin that the trainer sizes its slab workspace for the worst batch 1..cfg.batch) */
 int cmoop_wgrad_slices(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t* out);
@@ -129,6 +141,10 @@ int cmoop_standardize_apply(float* x_dev, int64_t rows, int32_t cols, const doub
 int cmoop_profile_reset(void);
 int cmoop_profile_count(int32_t* out);
 int cmoop_profile_entry(int32_t i, char* name, int32_t name_cap, int64_t* launches, double* total_ms, double* total_flops);
+/* launch-path variants of the sampled launches: instantiation name + "+sk" (split-K slabs and combine) / "+bal" /
+ * "+stats" (BatchNorm statistics in the epilogue) / "+tab" (row-table operand loader) / "+slabs" (wgrad row slices) */
+int cmoop_profile_variant_count(int32_t* out);
+int cmoop_profile_variant(int32_t i, char* name, int32_t name_cap);
 
 /* ---- single-candidate session (parity tests, smoke): one net on the library's stream */
 typedef struct cmoop_net cmoop_net;
@@ -143,6 +159,24 @@ int cmoop_net_train_step(cmoop_net* net, const float* x_dev, const int32_t* y_de
 int cmoop_net_evaluate(cmoop_net* net, const float* x_dev, const int32_t* y_dev, int64_t n, double* loss_sum,
                        int64_t* correct, int32_t* preds_dev);
 int cmoop_net_train_metrics(cmoop_net* net, double* loss_sum, int64_t* correct, int32_t reset);
+/* Full training state of the net (host arrays of cmoop_net_total_params floats; any pointer may be NULL): parameters in
+ * canonical order INCLUDING the BatchNorm moving statistics, Adam's m and v in the same layout (zero in the
+ * non-trainable slots), optimizer.iterations and the global train-step count that keys the dropout masks.  With these a
+ * checker can re-synchronise with the GPU at every epoch boundary of Model.fit (nsga_penalty.py:383) instead of
+ * comparing two long, chaotic fp32 trajectories at their ends. */
+int cmoop_net_get_state(cmoop_net* net, float* params, float* adam_m, float* adam_v, int64_t* iterations, int64_t* steps);
+int cmoop_net_set_state(cmoop_net* net, const float* params, const float* adam_m, const float* adam_v, int64_t iterations,
+                        int64_t steps);
+/* rows the resident training tensor holds: gathered row indices are clamped into [0, n_rows) (0 = unknown, no clamp) */
+int cmoop_net_set_gather_rows(cmoop_net* net, int64_t n_rows);
+/* ONE epoch of Model.fit on the trainer's own path: epoch permutation of (seed, epoch) computed on the device when
+ * cfg.shuffle, ceil(n_train / batch) steps driven by the device-resident step state, last partial batch kept. */
+int cmoop_net_run_epoch(cmoop_net* net, const float* x_train_dev, const int32_t* y_train_dev, int64_t n_train, int32_t epoch);
+/* evaluate_individual's fit + read-outs (nsga_penalty.py:377-392) on THIS net -- the body of cmoop_eval_population's
+ * per-candidate work -- with the per-epoch validation history (first hist_cap epochs), the epoch EarlyStopping took its
+ * best weights from (-1: none / early_stop off) and the epochs run. */
+int cmoop_net_fit(cmoop_net* net, const cmoop_dataset* ds, int32_t hist_cap, double* val_loss_hist, double* val_acc_hist,
+                  int32_t* epochs_run, int32_t* best_epoch, double* acc, double* fpr, double* val_loss);
 int cmoop_epoch_permutation(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out_host);
 /* the same permutation computed on the GPU (what the trainer uses: no host sort / H2D copy per epoch); n <= 262144 */
 int cmoop_epoch_permutation_device(uint32_t seed, uint32_t epoch, int64_t n, int32_t* out_dev);
@@ -154,10 +188,30 @@ int cmoop_conv_fwd(const float* x_dev, const float* w_dev, const float* bias_dev
 /* dx = dgrad(dy) (optionally masked by x > 0), dw[Cout][KS][KS][Cin], db[Cout] */
 int cmoop_conv_bwd(const float* x_dev, const float* w_dev, const float* dy_dev, float* dx_dev, float* dw_dev, float* db_dev,
                    int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t mask_relu);
+/* The same two operations launched EXACTLY as the trainer launches them (Net::forward / Net::backward): row-table operand
+ * loader, split-K workspace, flip-transposed dgrad operand prepared up front, weight-gradient slabs + fixed-order slice
+ * sum, and -- forward, col_sum != NULL -- the BatchNorm batch statistics taken in the conv epilogue (per-tile partials
+ * summed here in float64 into col_sum / col_sumsq [Cout]; *stats_fused = 0 when the launch was split-K and the
+ * statistics came from the stand-alone reduction, as in the trainer).  Cin must be a power of two >= 16. */
+int cmoop_conv_fwd_trainer(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int32_t B, int32_t H,
+                           int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t relu, double* col_sum,
+                           double* col_sumsq, int32_t* stats_fused);
+int cmoop_conv_bwd_trainer(const float* x_dev, const float* w_dev, const float* dy_dev, float* dx_dev, float* dw_dev,
+                           float* db_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride,
+                           int32_t mask_relu);
+/* kernel instantiations (+ launch-path variant suffixes, see cmoop_profile_variant) the calling thread's last
+ * cmoop_conv_fwd* / cmoop_conv_bwd* call launched, ';'-separated */
+int cmoop_last_kernels(char* buf, int32_t cap);
 /* average ms per launch over `iters` back-to-back launches (HIP events on the library stream);
  * mode 0: forward implicit GEMM, 1: dgrad implicit GEMM (y holds dY, x receives dX), 2: wgrad MFMA kernel */
 int cmoop_conv_time(int32_t mode, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int32_t B,
                     int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t iters, double* avg_ms);
+/* MLP-head layers (Dense+ReLU ladder, nsga_penalty.py:306-330) on the dense.hip kernels: y[M][N] = x[M][K] w[N][K]^T + b
+ * (optional ReLU); dx (optionally masked by x > 0), dw[N][K], db[N].  K a multiple of 16. */
+int cmoop_dense_fwd(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int32_t M, int32_t N, int32_t K,
+                    int32_t relu);
+int cmoop_dense_bwd(const float* x_dev, const float* w_dev, const float* dy_dev, float* dx_dev, float* dw_dev, float* db_dev,
+                    int32_t M, int32_t N, int32_t K, int32_t mask_relu);
 int cmoop_maxpool_fwd(const float* x_dev, float* y_dev, uint8_t* arg_dev, int32_t B, int32_t H, int32_t W, int32_t C);
 int cmoop_maxpool_bwd(const float* dy_dev, const uint8_t* arg_dev, const float* y_dev, float* dx_dev, int32_t B, int32_t H,
                       int32_t W, int32_t C, int32_t mask_y_pos);

@@ -204,6 +204,26 @@ class OracleNet:
                 off += t.numel()
         assert off == len(flat)
 
+    def get_state(self) -> dict:
+        """Full training state in the layout of the C ABI's cmoop_net_get_state (Adam moments zero in the non-trainable slots)."""
+        def flat(d):
+            return np.concatenate([(d[n] if n in d else torch.zeros_like(self.T[n])).detach().numpy().ravel() for n in self.names])
+        return {"params": self.get_flat(), "m": flat(self.m), "v": flat(self.v), "iterations": self.iterations, "steps": self.step}
+
+    def set_state(self, state: dict) -> None:
+        """Load parameters (incl. BatchNorm moving statistics), Adam m / v, optimizer.iterations and the dropout step
+        counter -- e.g. the GPU net's state at an epoch boundary (tests re-synchronise there)."""
+        self.set_flat(state["params"])
+        off = 0
+        with torch.no_grad():
+            for n in self.names:
+                k = self.T[n].numel()
+                if n in self.m:
+                    for dst, key in ((self.m[n], "m"), (self.v[n], "v")):
+                        dst.copy_(torch.from_numpy(np.asarray(state[key][off:off + k], np.float32).reshape(dst.shape)).to(dst.dtype))
+                off += k
+        self.iterations, self.step = int(state["iterations"]), int(state["steps"])
+
     def grads_flat(self) -> np.ndarray:
         out = []
         for n in self.names:
@@ -332,6 +352,37 @@ class OracleNet:
             corr += int((pr == yy).sum())
             preds.append(pr.numpy())
         return tot / max(n, 1), corr / max(n, 1), np.concatenate(preds) if preds else np.zeros(0, np.int64)
+
+
+def run_epoch(net: OracleNet, Xtr, ytr, epoch: int) -> Tuple[float, int]:
+    """One epoch of Model.fit: the seeded permutation of (seed, epoch), batches of cfg.batch, last partial batch kept.
+    Returns (sum of per-sample training losses, correct)."""
+    n = len(Xtr)
+    ytr = np.asarray(ytr).ravel()
+    perm = orng.epoch_permutation(net.seed, epoch, n) if net.cfg.shuffle else np.arange(n, dtype=np.int32)
+    ls, cs = 0.0, 0
+    for s in range(0, n, net.cfg.batch):
+        idx = perm[s:s + net.cfg.batch]
+        l, c = net.train_step(Xtr[idx], ytr[idx])
+        ls += l
+        cs += c
+    return ls, cs
+
+
+class EarlyStopping:
+    """keras/src/callbacks/early_stopping.py (3.6) with monitor='val_loss', min_delta=0, as the reference configures it
+    (nsga_penalty.py:382): feed one validation loss per epoch; ``update`` returns True when training stops."""
+
+    def __init__(self, patience: int):
+        self.patience, self.best, self.wait, self.best_epoch, self.epoch = patience, float("inf"), 0, -1, -1
+
+    def update(self, val_loss: float) -> bool:
+        self.epoch += 1
+        self.wait += 1
+        if val_loss < self.best:
+            self.best, self.best_epoch, self.wait = val_loss, self.epoch, 0
+            return False
+        return self.wait >= self.patience and self.epoch > 0
 
 
 def fit(net: OracleNet, Xtr, ytr, Xval, yval, max_steps: Optional[int] = None):

@@ -23,6 +23,10 @@ Fixtures (inputs + expected outputs of the reference functions):
                           ("Tchebycheff s_rank.ipynb") -- row N3
   surrogate_golden.json   SurrogateManager (sa_nsga_local.py:169-234) + select_infill_points
                           (sa_nsga_penalty.py:472-518) under a fixed numpy seed -- row N2
+  prepare_dataset_golden.json  load_data + prepare_dataset of nsga_penalty.py:57-155 (StandardScaler RE-FIT on every
+                          split, quirk Q1) and of mobo_penalty.py:32-82 (fit on train only), executed on six small .npy
+                          files written to a temp dir with the installed scikit-learn: inputs, output arrays, shapes,
+                          dtypes -- rows a1 / a2
 """
 import ast
 import json
@@ -295,6 +299,40 @@ def gen_metrics():
     print("metrics_golden.json", len(cases), "cases")
 
 
+def gen_prepare_dataset():
+    """The reference's OWN load_data + prepare_dataset (NumPy + sklearn.preprocessing.StandardScaler, both importable
+    here) run on six .npy files of the layout nsga_penalty.py:64-71 reads.  float32 and float64 feature files: the
+    reference stores what StandardScaler returns (same dtype as its input for floating input)."""
+    import tempfile
+    from sklearn.preprocessing import StandardScaler
+    rs = np.random.RandomState(85155)
+    cases = []
+    for dtype in ("float32", "float64"):
+        n, T, F = {"train": 7, "val": 5, "test": 4}, 6, 8
+        raw = {k: (2.5 + (1.0 + 0.3 * np.arange(F)) * rs.randn(n[k], T, F) + (0.8 if k == "val" else 0.0)).astype(dtype) for k in n}
+        raw["train"][:, :, 3] = 1.25                    # a constant feature: StandardScaler's zero-variance -> scale 1 handling
+        lab = {k: rs.randint(0, 10, size=n[k]).astype(np.int64) for k in n}
+        with tempfile.TemporaryDirectory() as d:
+            for k, fn in (("train", "train"), ("val", "val"), ("test", "test")):
+                np.save(os.path.join(d, f"X_{fn}.npy"), raw[k])
+                np.save(os.path.join(d, f"y_{fn}.npy"), lab[k])
+            rec = {"dtype": dtype, "T": T, "F": F,
+                   "inputs": {f"X_{k}": raw[k].astype(np.float64).tolist() for k in n} | {f"y_{k}": lab[k].tolist() for k in n}}
+            for script, tag in (("nsga_penalty.py", "refit"), ("mobo_penalty.py", "train_only")):
+                ns = extract(script, ["load_data", "prepare_dataset"], dict(StandardScaler=StandardScaler))
+                X_train, y_train, X_val, y_val, X_test, y_test = ns["prepare_dataset"](d)
+                rec[tag] = {"source": script,
+                            "X_train": np.asarray(X_train, np.float64).tolist(), "X_val": np.asarray(X_val, np.float64).tolist(),
+                            "X_test": np.asarray(X_test, np.float64).tolist(),
+                            "y_train": np.asarray(y_train).tolist(), "y_val": np.asarray(y_val).tolist(), "y_test": np.asarray(y_test).tolist(),
+                            "X_shape": list(X_train.shape), "y_shape": list(y_train.shape), "X_dtype": str(X_train.dtype), "y_dtype": str(y_train.dtype)}
+            cases.append(rec)
+    json.dump({"source": "nsga_penalty.py:57-155 (load_data, prepare_dataset: fit_transform per split); mobo_penalty.py:32-82 (fit on train only); "
+                         "executed with the installed scikit-learn's StandardScaler on six temp .npy files",
+               "cases": cases}, open(os.path.join(OUT, "prepare_dataset_golden.json"), "w"))
+    print("prepare_dataset_golden.json", len(cases), "cases")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -304,3 +342,4 @@ if __name__ == "__main__":
     gen_nsga_ops()
     gen_surrogate()
     gen_metrics()
+    gen_prepare_dataset()

@@ -96,6 +96,12 @@ def test_gpus_2_starts_two_ranks_itself_and_reports_them():
     per_rank = d["config"]["candidates_per_rank_last_step"]
     # 8 workers per rank start with the 8 + 8 items of the deterministic deal; the other 24 go through the shared counter
     assert len(per_rank) == 2 and sum(per_rank) == 40 and min(per_rank) >= 8, per_rank
+    # the N > 1 line explains itself -- per-rank candidates, busy seconds, counter round trips, all-gather
+    mg = d["multi_gpu"]["per_rank"]
+    assert [m["rank"] for m in mg] == [0, 1] and [m["candidates"] for m in mg] == per_rank
+    assert all(m["dealt_at_start"] == 8 and m["busy_wall_s"] > 0 and m["all_gather_ms"] > 0 for m in mg)
+    assert sum(m["store_fetch_adds"] for m in mg) >= 24 and all(m["store_add_us_mean"] > 0 for m in mg if m["store_fetch_adds"])
+    assert d["config"]["protocol"] == "fixed" and d["config"]["epochs_per_candidate"] == 10      # E_fixed = 10 is the default
 
 
 def test_gpus_8_rehearsal_deals_five_candidates_to_every_rank():
@@ -118,3 +124,44 @@ def test_world_size_mismatch_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], capture_output=True, text=True,
                        timeout=120, env=env)
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
+
+
+def test_spawn_path_counts_gpus_without_touching_hip(monkeypatch):
+    """`--gpus N` without torchrun must not initialise HIP in the parent before it starts the ranks --
+    torch.cuda.device_count() may fall back to hipGetDeviceCount.  The parent counts devices from the visibility variables
+    or the KFD topology only, refuses to spawn under rocprofv3 (whose preloaded library has already initialised the GPU),
+    and never calls into torch.cuda."""
+    import argparse
+
+    def boom(*a, **k):
+        raise AssertionError("the spawn path must not call torch.cuda")
+    monkeypatch.setattr(torch.cuda, "device_count", boom)
+    monkeypatch.setattr(torch.cuda, "is_available", boom)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    assert bench.count_visible_gpus() == 2
+    args = argparse.Namespace(gpus=4, same_device=False, stub=False)
+    assert bench.spawn_ranks(args, ["--gpus", "4"]) == 2                      # 4 wanted, 2 visible: refused before any spawn
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.count_visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    n = bench.count_visible_gpus()
+    assert n is None or n >= 0                                                # sysfs topology (absent in this container -> None or 0)
+    monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")
+    assert bench.running_under_rocprof()
+    assert bench.spawn_ranks(argparse.Namespace(gpus=2, same_device=True, stub=True), ["--gpus", "2", "--stub"]) == 2   # refused under a profiler
+
+
+def test_world_one_under_torchrun_is_the_plain_n1_path():
+    """VERDICT r2 item 10 (SCALE-vs-BENCH cross-check): the driver's N=1 SCALE point may come through torchrun with
+    WORLD_SIZE=1; it must be the same code path as plain `--gpus 1` (no process group, no collective): same workload
+    description, same schedule fields."""
+    outs = []
+    for env_extra in ({}, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"}):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--stub", "--steps", "1", "--warmup", "1",
+                            "--budget-s", "20", "--stub-ms-per-gflop", "2"], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0]))
+    a, b = outs
+    assert a["config"] == b["config"] and a["n_gpus"] == b["n_gpus"] == 1 and "multi_gpu" not in a and "multi_gpu" not in b

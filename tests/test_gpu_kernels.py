@@ -330,6 +330,62 @@ def test_prepare_dataset_modes_vs_oracle_scaler(mode):
     assert c is None and np.abs(b.cpu().numpy() - ofe.scaler_transform(raw[1], *ofe.scaler_fit(raw[1]))).max() < 1e-5
 
 
+def test_prepare_dataset_on_the_gpu_matches_the_reference_executed_fixture(golden_dir):
+    """frontend.prepare_dataset ('refit' = nsga_penalty.py:103-141, 'train_only' = mobo_penalty.py:57-82) against the outputs
+    of the reference's own prepare_dataset executed in the build container (tests/golden/prepare_dataset_golden.json):
+    1e-5 absolute on the standardised values (float64 statistics on the device, fp32 storage), zero-variance column -> 0."""
+    import json
+    from cmoop_audio_processing_amd import frontend as fe
+    fx = json.load(open(os.path.join(golden_dir, "prepare_dataset_golden.json")))
+    for case in fx["cases"]:
+        for mode in ("refit", "train_only"):
+            d = [dev(np.asarray(case["inputs"][k], np.float32)) for k in ("X_train", "X_val", "X_test")]
+            fe.prepare_dataset(d[0], d[1], d[2], mode=mode)
+            for t, k in zip(d, ("X_train", "X_val", "X_test")):
+                want = np.asarray(case[mode][k], np.float64)[..., 0]
+                assert np.abs(t.cpu().numpy() - want).max() < 1e-5, (case["dtype"], mode, k)
+            assert float(d[0][:, :, 3].abs().max()) == 0.0
+
+
+def test_npy_files_to_objectives_is_one_path(tmp_path):
+    """Row N4 / a1 as ONE path (VERDICT r2 item 4 of 'missing'): six .npy files as nsga_penalty.py:64-71 reads them ->
+    datasets.load_npy_splits (labels get their trailing axis, :74-76) -> frontend.prepare_dataset('refit') on the GPU
+    (:103-141) -> PopulationEvaluator.compute_objectives_and_constraints (:418-442), against the same chain on the oracle
+    (numpy loader semantics, oracle scaler, oracle evaluate_individual): size bit-exact, accuracy / FPR at the north-star
+    gate 1e-3, CV arithmetic identical."""
+    from cmoop_audio_processing_amd import EvalConfig, PopulationEvaluator, datasets as D, frontend as fe, genes as G
+    from oracle import frontend as ofe, metrics as OM, net as ON
+    rs = np.random.RandomState(12)
+    classes, T, F = 10, 21, 12
+    f, t = np.arange(F)[None, :], np.arange(T)[:, None]
+    proto = np.stack([np.sin(2 * np.pi * (1 + c % 5) * f / F + 0.7 * c) * np.cos(2 * np.pi * (1 + c // 5) * t / T) + (c - 5) / 10 for c in range(classes)])
+    for name, n in (("train", 160), ("val", 96), ("test", 32)):
+        y = rs.randint(0, classes, n)
+        np.save(tmp_path / f"X_{name}.npy", (3.0 + 2.0 * (proto[y] + 0.3 * rs.randn(n, T, F))).astype(np.float32))   # unscaled on disk
+        np.save(tmp_path / f"y_{name}.npy", y.astype(np.int64))
+    X_train, X_test, X_val, y_train, y_test, y_val = D.load_npy_splits(str(tmp_path))
+    assert y_train.shape == (160, 1) and X_train.shape == (160, T, F)
+    Xtr_d, Xva_d, Xte_d = dev(X_train), dev(X_val), dev(X_test)
+    fe.prepare_dataset(Xtr_d, Xva_d, Xte_d, mode="refit")
+    cfg = EvalConfig.preset("nsga_penalty", epochs=3, batch=32, eval_batch=64, seed=4, n_slots=2, early_stop=False)
+    ev = PopulationEvaluator(Xtr_d[..., None], y_train, Xva_d[..., None], y_val, cfg)          # [N,T,F,1] / (N,1), as the reference hands over
+    pop = [G.gene_to_hparams((16, 3, 0, 1, 1, 0)), G.gene_to_hparams((16, 5, 0, 2, 2, 0))]
+    res = ev.compute_objectives_and_constraints(pop)
+    # the oracle's chain
+    Xo_tr = ofe.scaler_transform(X_train, *ofe.scaler_fit(X_train))
+    Xo_va = ofe.scaler_transform(X_val, *ofe.scaler_fit(X_val))                               # quirk Q1: re-fit on validation
+    assert np.abs(Xtr_d.cpu().numpy() - Xo_tr).max() < 1e-5 and np.abs(Xva_d.cpu().numpy() - Xo_va).max() < 1e-5
+    ocfg = ON.OracleConfig(variant=0, classes=classes, epochs=3, batch=32, early_stop=False, restore_best=False, acc_readout="last",
+                           fpr_variant=OM.FPR_V1_QUIRK)
+    for i, (hp, r) in enumerate(zip(pop, res)):
+        g = G.normalize_hparams(hp)
+        acc, size, fpr, _ = ON.evaluate_individual(g, ocfg, Xo_tr, y_train, Xo_va, y_val, seed=cfg.seed + i)
+        want = OM.assemble(hp, acc, size, fpr, cfg.min_accuracy, cfg.max_model_size, cfg.max_fpr)
+        assert r["objs"][1] == want["objs"][1] == G.model_size_mb(g, 0, classes)
+        assert abs(r["objs"][0] - want["objs"][0]) <= 1e-3 and abs(r["objs"][2] - want["objs"][2]) <= 1e-3, (r, want)
+        assert abs(r["CV"] - want["CV"]) <= 2e-3 and r["hparams"] is hp
+
+
 def test_frontend_edge_cases():
     from cmoop_audio_processing_amd import frontend as fe
     from oracle import frontend as ofe

@@ -235,9 +235,50 @@ def test_birdclef_shaped_path_config3():
     assert gate(acc, o_acc, b_acc) and gate(fpr, o_fpr, b_fpr) and ev.last_epochs_run[0] in (o_epochs, b_epochs)
 
 
+def test_birdclef_shaped_population_config3():
+    """BASELINE configs[3] beyond one gene: 8 random genes (one forced to 64 filters) of the DS-CNN-style
+    search space on BirdCLEF-shaped data -- 128x128 patches, 11 classes, topology B, features UNSCALED (prepare mode
+    'none', sa_nsga_penalty.py:61-85), stratified 50/25/25 split (:71-85), batch 64 (:106), the script's own protocol.
+    Properties at that size: size_mb bit-exact for all 8, results bit-identical across the number of candidates in
+    flight; oracle parity (every epoch re-synchronised) on the cheapest candidate."""
+    import random
+    from cmoop_audio_processing_amd import datasets, frontend
+    classes, T, F = 11, 128, 128
+    rs = np.random.RandomState(17)
+    y_all = np.repeat(np.arange(classes), 24).astype(np.int32)
+    proto = rs.randn(classes, T, F).astype(np.float32)
+    X_all = (3.0 + 2.0 * (0.8 * proto[y_all] + rs.randn(len(y_all), T, F))).astype(np.float32)
+    Xtr, ytr, Xva, yva, Xte, yte = datasets.stratified_50_25_25(X_all, y_all, random_state=42)
+    assert len(Xtr) == 132 and len(Xva) == 66
+    Xtr_d, Xva_d = torch.from_numpy(Xtr).cuda(), torch.from_numpy(Xva).cuda()
+    frontend.prepare_dataset(Xtr_d, Xva_d, None, mode="none")                       # quirk Q2: no scaling
+    assert np.array_equal(Xtr_d.cpu().numpy(), Xtr)
+    rng = random.Random(3)
+    pop = [G.random_hparams(rng) for _ in range(8)]
+    pop[0] = dict(pop[0], filters=64, residual_blocks=2)
+    genes = [G.normalize_hparams(hp) for hp in pop]
+    base = dict(classes=classes, epochs=2, patience=2, batch=64, eval_batch=64, seed=6)
+    res = {}
+    for slots in (4, 2):
+        ev = PopulationEvaluator(Xtr_d, ytr, Xva_d, yva, EvalConfig.preset("sa_nsga_penalty", n_slots=slots, **base))
+        res[slots] = ev.compute_objectives_and_constraints(pop)
+    assert [r["objs"] for r in res[4]] == [r["objs"] for r in res[2]] and [r["CV"] for r in res[4]] == [r["CV"] for r in res[2]]
+    for g, r in zip(genes, res[4]):
+        acc, size, fpr = -r["objs"][0], r["objs"][1], r["objs"][2]
+        assert size == G.model_size_mb(g, 1, classes) and 0.0 <= acc <= 1.0 and 0.0 <= fpr <= 1.0
+        assert r["CV"] == max(0.0, 0.75 - acc) + max(0.0, size - 2.5) + max(0.0, fpr - 0.09)
+    i = min(range(8), key=lambda k: G.fwd_flops_per_sample(genes[k], 1, classes, T, F))
+    cfg = EvalConfig.preset("sa_nsga_penalty", n_slots=1, **base)
+    # unscaled inputs (mean 3) put a common offset into every first-layer sum: fp32 summation-order noise is ~4x that of
+    # standardised features (see test_birdclef_shaped_path_config3), hence 4e-4 on the per-epoch validation loss
+    resynchronised_fit_check(genes[i], cfg, Xtr, ytr, Xva, yva, cfg.seed + i,
+                             expected=(-res[4][i]["objs"][0], res[4][i]["objs"][2], ev.last_epochs_run[i]), loss_tol=4e-4, tag="configs[3]")
+
+
 PROTOCOLS = [
     ("nsga_penalty", (16, 3, 0, 1, 1, 0)),       # A, last-epoch accuracy, no restore, y_true quirk
     ("sa_nsga_local", (16, 5, 0, 2, 1, 0)),      # B, V3
+    ("mobo_penalty", (16, 3, 0, 1, 2, 0)),       # A, restore_best + LAST-epoch accuracy + FPR of the restored weights (mobo_penalty.py:227,236,239: Q6)
 ]
 CHAOTIC = ("sa_nsga_penalty", (16, 3, 1, 1, 2, 1))   # B, restore_best, evaluate(), V1 -- BatchNorm + dropout
 
@@ -276,30 +317,119 @@ def test_protocol_parity_batchnorm_dropout_short_horizon():
     assert gate(acc, a[0], b[0]) and gate(fpr, a[2], b[2])
 
 
-def test_protocol_parity_batchnorm_dropout_full_protocol_is_statistical():
-    """The same candidate through the full early-stopped protocol (25 epochs, patience 2: ~140 steps).  Here training is
-    CHAOTIC in the numerical sense: the oracle's own two CPU conv algorithms (same arithmetic, another fp32 summation
-    order) end 4 of 128 predictions apart, and on the GPU a one-ulp change in Adam's rounding of m (FMA contraction chosen
-    differently by the compiler in two kernels, since pinned) moved the result from 0.461 / 23 epochs to 0.508 / 25 epochs.
-    A single run therefore cannot be gated at 1e-3 against anything.  What is pinned instead, over 3 seeds:
-    every GPU result lies within the oracle's range widened by three times the oracle's mean own spread, the stopping
-    epoch within the patience of an oracle run, and the seed-averaged accuracy / FPR within 0.04 / 0.01 of the oracle's."""
-    preset, gene = CHAOTIC
-    runs = [protocol_case(preset, gene, 25, 2, seed=s) for s in (11, 12, 13)]
-    for k, name, mean_gate in ((0, "accuracy", 0.04), (1, "fpr", 0.01)):
-        ok = 0 if k == 0 else 2                      # column of the oracle tuple
-        spread = max(1.0 / 128 if k == 0 else 1e-3, float(np.mean([abs(a[ok] - b[ok]) for _, a, b in runs])))
-        for (gpu, a, b) in runs:
-            lo, hi = min(a[ok], b[ok]) - 3 * spread, max(a[ok], b[ok]) + 3 * spread
-            assert lo <= gpu[k] <= hi, (name, gpu[k], a[ok], b[ok], spread)
-        g_mean = float(np.mean([gpu[k] for gpu, _, _ in runs]))
-        o_mean = float(np.mean([0.5 * (a[ok] + b[ok]) for _, a, b in runs]))
-        print(f"mean {name} over seeds: gpu {g_mean:.4f} oracle {o_mean:.4f} (mean own spread {spread:.4f})")
-        assert abs(g_mean - o_mean) <= mean_gate, (name, g_mean, o_mean)
-    for (gpu, a, b) in runs:
-        assert min(abs(gpu[2] - a[3]), abs(gpu[2] - b[3])) <= 2, (gpu[2], a[3], b[3])
-        assert 0.3 <= a[0] <= 0.97
+def _es_replay(cfg, val_loss_history):
+    """epochs_run / best_epoch that Keras' EarlyStopping (oracle.net.EarlyStopping, the restatement oracle.net.fit uses)
+    produces from a validation-loss history"""
+    if not cfg.early_stop:
+        return len(val_loss_history), -1
+    es = ON.EarlyStopping(cfg.patience)
+    for e, vl in enumerate(val_loss_history):
+        if es.update(float(vl)):
+            return e + 1, es.best_epoch
+    return len(val_loss_history), es.best_epoch
 
+
+def resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=None, loss_tol=1e-4, pred_tol=1, stat_tol=1e-5, tag=""):
+    """Tight end-to-end parity of the FULL early-stopped protocol without comparing two long chaotic fp32 trajectories at
+    their ends: the GPU and the oracle are RE-SYNCHRONISED at every epoch boundary.
+
+    1. The product's fit + read-outs run on a session net (cmoop_net_fit = the body of cmoop_eval_population's per-candidate
+       work).  Its control flow is checked exactly: Keras' EarlyStopping fed the GPU's own validation-loss history must stop
+       at the same epoch and pick the same best epoch; the accuracy read-out is the history's last entry ('last') or comes
+       from the final weights ('evaluate'); `expected` (accuracy, fpr, epochs_run from PopulationEvaluator) must be
+       reproduced bit for bit.
+    2. The oracle loads the GPU's FINAL state (best weights restored when the script asks for it) and recomputes the
+       read-outs: predictions differ in at most one validation clip, and where none differs accuracy / FPR are equal.
+    3. A second GPU net replays the run epoch by epoch (cmoop_net_run_epoch, the trainer's own device-state path); BEFORE
+       each epoch the oracle loads the GPU's full state (weights, BatchNorm moving statistics, Adam m / v, iteration and
+       dropout counters), both run the epoch on the same permutation and masks, and after it: the GPU's validation loss
+       equals the history of run 1 BIT FOR BIT (it is the same trajectory), |val loss GPU - oracle| <= loss_tol (relative,
+       floor 1), predictions differ in <= 1 clip, BatchNorm moving statistics agree to 1e-5 of their largest entry.
+       The horizon of every comparison is one epoch, so rounding differences cannot be amplified into different runs, yet
+       every epoch of the protocol as the product runs it is checked."""
+    import torch as _t
+    T, F = int(Xtr.shape[1]), int(Xtr.shape[2])
+    Xtr_d, ytr_d = _t.from_numpy(Xtr).cuda(), _t.from_numpy(ytr.astype(np.int32)).cuda()
+    Xva_d, yva_d = _t.from_numpy(Xva).cuda(), _t.from_numpy(yva.astype(np.int32)).cuda()
+    v = G.VARIANT_NAMES[cfg.variant]
+    oc = ocfg(cfg)
+    with NetSession(gene, cfg, T, F, seed) as net:
+        fit = net.fit(Xtr_d, ytr_d, Xva_d, yva_d)
+        final = net.get_state()
+    hist_l, hist_a, E = fit["val_loss_history"], fit["val_accuracy_history"], fit["epochs_run"]
+    assert len(hist_l) == E >= 1 and np.isfinite(hist_l).all()
+    stop, best = _es_replay(cfg, hist_l)
+    assert (stop, best) == (E, fit["best_epoch"]), f"early stopping differs from Keras' on the same history: {(stop, best)} vs {(E, fit['best_epoch'])}"
+    if expected is not None:
+        assert (fit["acc"], fit["fpr"], E) == tuple(expected), (fit["acc"], fit["fpr"], E, expected)
+    onet = ON.OracleNet(gene, oc, seed)
+    onet.set_state(final)
+    l_o, a_o, p_o = onet.evaluate(Xva, yva)
+    fpr_o = OM.calculate_fpr(np.asarray(yva).ravel(), p_o, cfg.classes, oc.fpr_variant)
+    acc_o = hist_a[-1] if cfg.acc_readout == "last" else a_o
+    restored = cfg.early_stop and cfg.restore_best and best != E - 1
+    if cfg.acc_readout == "last":
+        assert fit["acc"] == hist_a[-1]
+    one = pred_tol / len(yva)
+    assert abs(fit["acc"] - acc_o) <= one + 1e-12 and abs(fit["fpr"] - fpr_o) <= max(1e-3, one) + 1e-12, (fit, acc_o, fpr_o)
+    worst = dict(loss=0.0, preds=0, stats=0.0)
+    tensors = G.param_tensors(gene, v, cfg.classes)
+    with NetSession(gene, cfg, T, F, seed) as net:
+        onet = ON.OracleNet(gene, oc, seed)
+        for e in range(E):
+            onet.set_state(net.get_state())
+            net.run_epoch(Xtr_d, ytr_d, e)
+            ON.run_epoch(onet, Xtr, ytr, e)
+            l_g, a_g, p_g = net.evaluate(Xva_d, yva_d)
+            l_o, a_o, p_o = onet.evaluate(Xva, yva)
+            assert l_g == hist_l[e] and a_g == hist_a[e], f"epoch {e}: the replayed GPU run left the product's trajectory ({l_g} vs {hist_l[e]})"
+            d_loss = abs(l_g - l_o) / max(1.0, abs(l_o))
+            d_pred = int((p_g.cpu().numpy() != p_o).sum())
+            pg, po, off, d_stat = net.get_params(), onet.get_flat(), 0, 0.0
+            for name, shape, role in tensors:
+                n = int(np.prod(shape))
+                if role in ("moving_mean", "moving_var"):
+                    # epoch 0 starts from Adam's zero state, where a conv bias in front of a BatchNorm (analytically zero
+                    # gradient) moves by +-lr per step with a rounding-noise sign on either side; the bias shifts the
+                    # batch mean, so moving_mean may differ by momentum-weighted 2 lr per step there -- and only there
+                    slack = 0.01 * 2.5 * cfg.lr * (-(-len(Xtr) // cfg.batch)) if (role == "moving_mean" and e == 0) else 0.0
+                    d = float(np.abs(pg[off:off + n] - po[off:off + n]).max())
+                    d_stat = max(d_stat, max(0.0, d - slack) / max(float(np.abs(po[off:off + n]).max()), 1e-3))
+                off += n
+            worst = dict(loss=max(worst["loss"], d_loss), preds=max(worst["preds"], d_pred), stats=max(worst["stats"], d_stat))
+            assert d_loss <= loss_tol and d_pred <= pred_tol and d_stat <= stat_tol, \
+                f"{tag} {gene} epoch {e}: val loss {l_g} vs {l_o} ({d_loss:.1e}), {d_pred} predictions differ, moving stats {d_stat:.1e}"
+    print(f"{tag} {gene} seed {seed}: {E} epochs (best {best}, restored {restored}) acc {fit['acc']:.4f} fpr {fit['fpr']:.4f}; "
+          f"worst per-epoch deviation: val loss {worst['loss']:.1e}, predictions {worst['preds']}, moving stats {worst['stats']:.1e}")
+    return fit
+
+
+RESYNC_PROTOCOLS = [
+    ("sa_nsga_penalty", (16, 3, 1, 1, 2, 1)),    # the BatchNorm + dropout candidate whose end-to-end run is chaotic (B, restore_best, evaluate(), V1)
+    ("mobo_penalty", (16, 3, 1, 1, 2, 1)),       # A, restore_best (mobo_penalty.py:227) + LAST-epoch accuracy (:236) + FPR of the restored weights (:239): quirk Q6
+    ("nsga_penalty", (32, 5, 1, 2, 3, 1)),       # A, BatchNorm + dropout, no restore, y_true quirk
+    ("sa_nsga_local", (16, 5, 0, 2, 1, 0)),      # B, V3
+    ("init_sa_nsga_local", (64, 3, 1, 3, 4, 1)), # B, 64 filters, R = 3: the K = 512 head
+]
+
+
+@pytest.mark.parametrize("preset,gene", RESYNC_PROTOCOLS)
+def test_full_protocol_resynchronised_every_epoch(preset, gene):
+    """The full early-stopped protocol of each reference script (25 epochs, patience 2, ~100-150 optimiser steps) gated
+    TIGHTLY at every epoch -- val loss 1e-4, <= 1 prediction, moving statistics 1e-5, early-stopping decisions exact --
+    by re-synchronising the oracle with the GPU at each epoch boundary (resynchronised_fit_check).  This replaces round
+    2's statistical band for the BatchNorm + dropout candidate (three seeds here, as there)."""
+    classes = 11 if preset == "sa_nsga_penalty" else 10
+    Xtr, ytr, Xva, yva = make_split(192, 128, 21, 12, classes, 21, noise=0.3, label_noise=0.25)
+    for seed in ((11, 12, 13) if preset == "sa_nsga_penalty" else (11,)):
+        cfg = EvalConfig.preset(preset, classes=classes, epochs=25, patience=2, batch=32, eval_batch=64, seed=seed, n_slots=1)
+        ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+        acc, size_mb, fpr = ev.evaluate_individual(G.gene_to_hparams(gene))
+        assert size_mb == G.model_size_mb(gene, G.VARIANT_NAMES[cfg.variant], classes)
+        fit = resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=(acc, fpr, ev.last_epochs_run[0]), tag=preset)
+        if preset == "mobo_penalty" and fit["best_epoch"] != fit["epochs_run"] - 1:
+            # Q6: accuracy is the LAST epoch's, FPR belongs to the RESTORED weights
+            assert fit["acc"] == fit["val_accuracy_history"][-1]
 
 
 def test_reference_input_shapes_at_the_boundary():
@@ -428,89 +558,76 @@ def _oracle_population_evaluator(cfg, Xtr, ytr, Xva, yva, dtype=torch.float32):
     return oracle_eval
 
 
-def _recording(evaluate):
+def _recording(ev):
+    """compute_objectives_and_constraints of a PopulationEvaluator, recording per call
+    [(gene, seed, accuracy, size_mb, fpr, epochs_run)] -- what a replay of the same candidates needs."""
     calls = []
 
     def wrapped(pop):
-        out = evaluate(pop)
-        calls.append([(G.normalize_hparams(r["hparams"]), -r["objs"][0], r["objs"][1], r["objs"][2]) for r in out])
+        first = ev.evals_done
+        out = ev.compute_objectives_and_constraints(pop)
+        calls.append([(G.normalize_hparams(r["hparams"]), ev.config.seed + first + i, -r["objs"][0], r["objs"][1], r["objs"][2],
+                       ev.last_epochs_run[i]) for i, r in enumerate(out)])
         return out
     return wrapped, calls
 
 
-def test_sa_nsga2_35_classes_on_gpu_vs_oracle_config2():
+def _replay_every_candidate(calls, cfg, Xtr, ytr, Xva, yva, tag, **tol):
+    """The GPU drove the search; every candidate it truly evaluated is now checked epoch by epoch against the oracle
+    (same gene, same seed; resynchronised_fit_check), its recorded objectives reproduced bit for bit."""
+    v = G.VARIANT_NAMES[cfg.variant]
+    n = 0
+    for call in calls:
+        for gene, seed, acc, size, fpr, epochs in call:
+            assert size == G.model_size_mb(gene, v, cfg.classes)                       # bit-exact (== in float64)
+            resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=(acc, fpr, epochs), tag=tag, **tol)
+            n += 1
+    return n
+
+
+def test_sa_nsga2_35_classes_gpu_search_replayed_on_the_oracle_config2():
     """BASELINE configs[2] at reduced size: the surrogate-assisted loop of sa_nsga_penalty.py:522-637 (topology B,
-    restore_best + evaluate(), infill 0.2, Kriging surrogate on the host) driven by the GPU evaluator on a 35-class
-    task, pop 8 / gen 2 -> 8 + 2*1 true evaluations, against the same seeded loop on the oracle.
-    * the initial population (the same 8 genes by construction): size bit-exact per candidate; the population's MEAN
-      accuracy and FPR inside the band of three equivalent oracle evaluations (fp32 mkldnn conv, fp32 native conv,
-      float64).  Per-candidate gates are meaningless here: in the take-off phase of a 35-class run the oracle differs
-      from ITSELF by up to 0.24 accuracy between its two conv algorithms (gene (64,3,0,3,1,1): 0.564 vs 0.321 after 6
-      epochs, measured), so no implementation can reproduce single candidates; the 1e-3 gate proper is
-      test_evaluate_individual_protocol_parity;
-    * the loop: same number of true evaluations; final-generation hypervolumes of the same order on a shared
-      reference point (one flipped validation prediction legitimately steers the Kriging infill choice to another gene)."""
+    restore_best + evaluate(), infill 0.2, Kriging surrogate on the host) driven by the GPU evaluator on a 35-class task,
+    pop 8 / gen 2 -> 8 + 2 * 1 true evaluations.  Round 2 ran a second, independent search on the oracle and compared
+    hypervolumes after the two had diverged (one flipped prediction re-routes the Kriging infill): a 0.5-2.0x gate.  Now the
+    GPU drives and the oracle REPLAYS: each of the 10 candidates the search evaluated is checked at every epoch of its
+    early-stopped run (val loss 1e-4, <= 1 prediction, moving statistics 1e-5, early-stopping decisions exact), and its
+    objectives as the search saw them are reproduced bit for bit -- so the search consumed correct numbers, whatever
+    route it took.  (The host loop itself is pinned by tests/golden/surrogate_golden.json.)"""
     from cmoop_audio_processing_amd import nsga, surrogate as S
     classes = 35
     cfg = EvalConfig.preset("sa_nsga_penalty", classes=classes, epochs=6, patience=2, batch=32, eval_batch=64, seed=5, n_slots=4)
     Xtr, ytr, Xva, yva = make_split(420, 140, 21, 12, classes, 61, noise=0.3, label_noise=0.1)
     ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
-    f_gpu, calls_gpu = _recording(ev.compute_objectives_and_constraints)
-    _, hist_gpu, n_gpu = S.sa_nsga2(f_gpu, 8, 2, infill_percent=0.2, seed=3)
-    f_cpu, calls_cpu = _recording(_oracle_population_evaluator(cfg, Xtr, ytr, Xva, yva))
-    _, hist_cpu, n_cpu = S.sa_nsga2(f_cpu, 8, 2, infill_percent=0.2, seed=3)
-    assert n_gpu == n_cpu == 8 + 2 * 1 and ev.evals_done == n_gpu
-    assert [c[0] for c in calls_gpu[0]] == [c[0] for c in calls_cpu[0]]
-    bands = []
-    for i, ((g_g, acc_g, size_g, fpr_g), (g_c, acc_c, size_c, fpr_c)) in enumerate(zip(calls_gpu[0], calls_cpu[0])):
-        band = oracle_band(g_c, cfg, Xtr, ytr, Xva, yva, cfg.seed + i)
-        assert band[0][0] == acc_c and band[0][2] == fpr_c           # the loop's oracle call is the band's first member
-        print(g_g, "gpu", (acc_g, fpr_g), "oracle band acc", [b[0] for b in band], "fpr", [b[2] for b in band])
-        assert size_g == size_c and 0.0 <= acc_g <= 1.0 and 0.0 <= fpr_g <= 1.0
-        bands.append(band)
-    for col, name in ((0, "accuracy"), (2, "FPR")):
-        means = [float(np.mean([band[v][col] for band in bands])) for v in range(3)]
-        gpu_mean = float(np.mean([c[1 if col == 0 else 3] for c in calls_gpu[0]]))
-        print(f"population mean {name}: gpu {gpu_mean:.4f}, oracle variants {means}")
-        assert gate(gpu_mean, *means, tol=0.02), (name, gpu_mean, means)
-    fr_g = [[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in hist_gpu[-1]]
-    fr_c = [[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in hist_cpu[-1]]
-    ref = nsga.shared_reference_point([fr_g, fr_c])
-    hv_g, hv_c = nsga.hypervolume(fr_g, ref), nsga.hypervolume(fr_c, ref)
-    print(f"SA-NSGA-II 35 classes: HV gpu {hv_g:.6f} oracle {hv_c:.6f}")
-    # the two searches evaluate different genes after the first infill (see above), so their fronts differ as two
-    # runs of the oracle with different conv algorithms do; same order of magnitude is all that can be asked here --
-    # the 1 % hypervolume gate at equal genes is test_hypervolume_parity_gpu_vs_oracle_search
-    assert hv_g > 0 and hv_c > 0 and 0.5 <= hv_g / hv_c <= 2.0
+    f_gpu, calls = _recording(ev)
+    _, hist, n_true = S.sa_nsga2(f_gpu, 8, 2, infill_percent=0.2, seed=3)
+    assert n_true == 8 + 2 * 1 == ev.evals_done and [len(c) for c in calls] == [8, 1, 1]
+    fronts = [[[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in h] for h in hist]
+    ref = nsga.shared_reference_point(fronts)
+    assert all(nsga.hypervolume(f, ref) > 0 for f in fronts)
+    assert _replay_every_candidate(calls, cfg, Xtr, ytr, Xva, yva, "configs[2]") == 10
 
 
-def test_memetic_sa_nsga2_bf16_on_gpu_vs_oracle_config4():
-    """BASELINE configs[4] at reduced size: the full memetic method of init_sa_nsga_local.py:388-470 (LHS init,
-    Kriging surrogate, Lamarckian LCB local search, infill 0.334) with the opt-in bf16-train arithmetic
-    (compute='bf16'), pop 8 / gen 2 on the GPU evaluator vs the same loop on the bf16 oracle.  bf16 nets are not
-    bit-comparable (a bf16 oracle differs from itself by 1e-2..1e-1 on one step's gradients), so the gate
-    is: same number of true evaluations, valid records, and hypervolume within 25 % -- the loop runs end to end on
-    the GPU path with the bf16 kernels."""
-    from cmoop_audio_processing_amd import nsga, surrogate as S
+def test_memetic_sa_nsga2_bf16_gpu_search_replayed_on_the_oracle_config4():
+    """BASELINE configs[4] at reduced size: the full memetic method of init_sa_nsga_local.py:388-470 (LHS init, Kriging
+    surrogate, Lamarckian LCB local search, infill 0.334) with the opt-in bf16-train arithmetic (compute='bf16'), pop 8 /
+    gen 2 on the GPU evaluator; every truly evaluated candidate replayed epoch by epoch on the bf16 oracle.  bf16 nets are
+    not comparable at fp32 tolerances even over one epoch (the bf16 oracle differs from itself by 1e-2..1e-1 on
+    ONE step's gradients when only torch's conv algorithm changes), so the per-epoch gates are: val loss 2e-2, <= 4 of 96
+    predictions, moving statistics 2e-3; control flow and read-outs exact as everywhere."""
+    from cmoop_audio_processing_amd import surrogate as S
     classes = 10
     cfg = EvalConfig.preset("init_sa_nsga_local", classes=classes, epochs=4, patience=2, batch=32, eval_batch=64, seed=8, n_slots=4,
                             compute="bf16")
     Xtr, ytr, Xva, yva = make_split(192, 96, 21, 12, classes, 71, noise=1.0)
     ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
-    kw = dict(infill_percent=0.334, seed=4, init="lhs", local_search=True)
-    _, hist_gpu, n_gpu = S.sa_nsga2(ev.compute_objectives_and_constraints, 8, 2, **kw)
-    assert n_gpu == 8 + 2 * 2 == ev.evals_done and len(hist_gpu) == 2 and all(len(h) == 8 for h in hist_gpu)
-    for h in hist_gpu:
+    f_gpu, calls = _recording(ev)
+    _, hist, n_true = S.sa_nsga2(f_gpu, 8, 2, infill_percent=0.334, seed=4, init="lhs", local_search=True)
+    assert n_true == 8 + 2 * 2 == ev.evals_done and len(hist) == 2 and all(len(h) == 8 for h in hist)
+    for h in hist:
         for rec in h:
             assert 0.0 <= rec["Accuracy"] <= 1.0 and rec["Size_MB"] > 0
-    _, hist_cpu, n_cpu = S.sa_nsga2(_oracle_population_evaluator(cfg, Xtr, ytr, Xva, yva), 8, 2, **kw)
-    assert n_cpu == n_gpu
-    f_gpu = [[[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in h] for h in hist_gpu]
-    f_cpu = [[[-r["Accuracy"], r["Size_MB"], r["FPR"]] for r in h] for h in hist_cpu]
-    ref = nsga.shared_reference_point(f_gpu + f_cpu)
-    hv_g, hv_c = nsga.hypervolume(f_gpu[-1], ref), nsga.hypervolume(f_cpu[-1], ref)
-    print(f"memetic bf16: HV gpu {hv_g:.6f} oracle {hv_c:.6f}")
-    assert abs(hv_g - hv_c) <= 0.25 * max(hv_c, 1e-12)
+    assert _replay_every_candidate(calls, cfg, Xtr, ytr, Xva, yva, "configs[4] bf16", loss_tol=2e-2, pred_tol=4, stat_tol=2e-3) == 12
 
 
 def test_population_schema_determinism_and_problem_shim():
@@ -641,40 +758,19 @@ def test_hypervolume_parity_gpu_vs_oracle_search():
         assert abs(hv_g - hv_c) <= 0.01 * max(hv_c, 1e-12)
 
 
-def test_hard_synthetic_set_gpu_deviates_no_more_than_the_oracle_does_from_itself():
-    """on the §8d synthetic set every candidate scores accuracy 1.0, so 'HV within 1 %' could not fail.
-    A search (pop 4, 2 generations, early stopping on) on the HARD variant of the set -- low SNR, neighbouring classes
-    share two of three partials (bench.synth_waveforms(hard=True)) -- through the real pipeline: HIP front end ->
-    StandardScaler -> GPU evaluator.  Accuracies spread from chance to 1.0.
+def test_hard_synthetic_set_search_replayed_epoch_by_epoch():
+    """on the section-8d synthetic set every candidate scores accuracy 1.0, so 'HV within 1 %' could not fail.
+    A search (pop 4, 2 generations, early stopping on, BatchNorm and dropout genes as drawn) on the HARD variant of the set
+    -- low SNR, neighbouring classes share two of three partials (bench.synth_waveforms(hard=True)) -- through the real
+    pipeline: HIP front end -> StandardScaler -> GPU evaluator.  Accuracies spread.
 
-    The GPU drives the search; every population it evaluated (initial population, offspring of generations 0 and 1: 12
-    evaluations) is replayed, same genes and same seeds, through the oracle in fp32 AND in float64 (same float32 initial
-    weights) -- two equivalent CPU evaluations of one algorithm whose rounding differs about as much as a GPU's does.
-    What round 2 measured on this task, and why the gate below is statistical: training here is numerically UNSTABLE for
-    every implementation.  The fp32 and float64 oracles end 5, 6 and 14 accuracy points apart on single candidates (0.869 vs
-    0.919; 0.788 vs 0.844; 0.938 vs 0.800) and their hypervolumes of one evaluated set differ by 16 % (2.74 vs 3.19); the
-    GPU lands ON the float64 oracle for one set (HV 4.459015 both), on the fp32 oracle for another and 23 % off both for the
-    third (one candidate early-stops at 0.86 where both oracles reach 0.97).  Candidates near chance take off late, the
-    validation set has 160 clips and patience is 2: one rounding difference moves the stopping epoch.  A 1 % hypervolume
-    gate on such a task is a lottery for ANY pair of implementations (it stays asserted where training is reproducible:
-    test_hypervolume_parity_gpu_vs_oracle_search, and the 1e-3 protocol gates).  Pinned here instead:
-      * the same genes reach both sides, sizes bit-exact, accuracies spread (the set has teeth);
-      * the GPU's mean |accuracy - fp32 oracle| and mean |FPR - fp32 oracle| over the 12 evaluations are no larger than
-        twice the float64 oracle's own (floors 0.01 / 0.002): measured 0.022 vs 0.026 for accuracy;
-      * summed hypervolume of the three evaluated sets within 25 % of the fp32 oracle's (measured -8.5 %; float64: +4.4 %).
-    BatchNorm and dropout are off for every candidate (with them on, the oracle's own two conv algorithms gave HV 0.096
-    and 0.144 on the same genes); the search itself runs only on the GPU side because independent searches diverge after
-    one flipped tournament (measured: generation-1 HV 0.061 vs 0.079)."""
+    Round 2 showed that end-of-run comparisons are a lottery on this task for ANY two implementations (the fp32 and float64
+    oracles end 5-14 accuracy points apart on single candidates; a 25 % hypervolume gate was all that held).  Instead the
+    GPU drives the search and each of its 12 true evaluations is replayed on the oracle with a re-synchronisation at every
+    epoch boundary (resynchronised_fit_check): val loss within 1e-4, <= 1 prediction, moving statistics 1e-5 per epoch,
+    early-stopping decisions and read-outs exact, the search's objectives reproduced bit for bit."""
     import bench
     from cmoop_audio_processing_amd import frontend, nsga
-
-    def reproducible(evaluate):
-        def f(pop):
-            res = evaluate([dict(hp, use_bn=False, use_dropout=False) for hp in pop])
-            for r, hp in zip(res, pop):
-                r["hparams"] = hp          # the search operators keep working on the caller's dicts
-            return res
-        return f
     wav, y = bench.synth_waveforms(480, 10, 7, torch.device("cuda"), n_samples=4000, chunk=160, hard=True, hard_snr_db=-6.0)
     feats = frontend.log_mel(wav)                                   # [480, 26, 40]
     Xtr_d, Xva_d = feats[:320].contiguous(), feats[320:].contiguous()
@@ -683,38 +779,13 @@ def test_hard_synthetic_set_gpu_deviates_no_more_than_the_oracle_does_from_itsel
     ytr, yva = y[:320].cpu().numpy(), y[320:].cpu().numpy()
     cfg = EvalConfig.preset("nsga_penalty", epochs=12, patience=2, batch=32, eval_batch=64, seed=3, n_slots=4, fpr_variant="v1")
     ev = PopulationEvaluator(Xtr_d, y[:320], Xva_d, y[320:], cfg)
-    f_gpu, calls_gpu = _recording(reproducible(ev.compute_objectives_and_constraints))
+    f_gpu, calls = _recording(ev)
     nsga.nsga2(f_gpu, 4, 2, seed=5)
-    assert len(calls_gpu) == 3 and all(len(c) == 4 for c in calls_gpu)
-    pops = [[G.gene_to_hparams(g) for g, *_ in call] for call in calls_gpu]
-
-    def replay(dtype):
-        f, calls = _recording(reproducible(_oracle_population_evaluator(cfg, Xtr, ytr, Xva, yva, dtype=dtype)))
-        for pop in pops:
-            f([dict(hp) for hp in pop])
-        return calls
-    calls_32, calls_64 = replay(torch.float32), replay(torch.float64)
-    flat = lambda calls: [r for call in calls for r in call]
-    g, o32, o64 = flat(calls_gpu), flat(calls_32), flat(calls_64)
-    assert [r[0] for r in g] == [r[0] for r in o32] and [r[2] for r in g] == [r[2] for r in o32]   # same genes, sizes bit-exact
-    for k in range(3):
-        print(f"set {k}: accuracy gpu / oracle fp32 / oracle fp64:",
-              [(round(a[1], 4), round(b[1], 4), round(c[1], 4)) for a, b, c in zip(calls_gpu[k], calls_32[k], calls_64[k])])
-    accs = sorted(r[1] for r in g)
+    assert len(calls) == 3 and all(len(c) == 4 for c in calls)
+    accs = sorted(r[2] for call in calls for r in call)
+    print("hard set accuracies:", [round(a, 3) for a in accs])
     assert accs[-1] - accs[0] >= 0.15, "the hard set must spread the accuracies"
-    for col, name, floor in ((1, "accuracy", 0.01), (3, "fpr", 0.002)):
-        d_gpu = float(np.mean([abs(a[col] - b[col]) for a, b in zip(g, o32)]))
-        d_o64 = float(np.mean([abs(a[col] - b[col]) for a, b in zip(o64, o32)]))
-        print(f"mean |{name} - fp32 oracle| over 12 evaluations: gpu {d_gpu:.4f}, float64 oracle {d_o64:.4f}")
-        assert d_gpu <= max(floor, 2.0 * d_o64), (name, d_gpu, d_o64)
-    fronts = lambda calls: [[[-acc, size, fpr] for _, acc, size, fpr in call] for call in calls]
-    f_g, f_32, f_64 = fronts(calls_gpu), fronts(calls_32), fronts(calls_64)
-    ref = nsga.shared_reference_point(f_g + f_32 + f_64)
-    hv = lambda f: [nsga.hypervolume(f[k], ref) for k in range(3)]
-    hv_g, hv_32, hv_64 = hv(f_g), hv(f_32), hv(f_64)
-    print("HV per evaluated set: gpu", [round(v, 4) for v in hv_g], "fp32 oracle", [round(v, 4) for v in hv_32],
-          "float64 oracle", [round(v, 4) for v in hv_64])
-    assert abs(sum(hv_g) - sum(hv_32)) <= 0.25 * sum(hv_32)
+    assert _replay_every_candidate(calls, cfg, Xtr, ytr, Xva, yva, "hard set") == 12
 
 
 def _cos(a, b):

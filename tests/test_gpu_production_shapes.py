@@ -1,0 +1,273 @@
+"""GPU parity ON THE SHAPES AND KERNEL INSTANTIATIONS THE BENCH RUNS.
+
+The pop-40 benchmark (BASELINE configs[1]: batch 64, 101x40 features, nsga_penalty.py:161,255-301) spends its time in a
+dozen implicit-GEMM instantiations on a handful of layer shapes.  Here every one of them is compared with a float64
+restatement (oracle.net.conv_same + autograd) THROUGH THE TRAINER'S OWN LAUNCH PATH (cmoop_conv_fwd_trainer /
+cmoop_conv_bwd_trainer: row-table operand loader, split-K workspace, BatchNorm statistics epilogue, weight-gradient
+slabs), whole nets are gradient-checked at 101x40 / batch 64 for the heaviest bench gene, and a coverage test asserts
+that every launch-path variant the pop-40 job samples was hit by one of these parity cases.
+
+Tolerances (fp32 MFMA = exact fmaf chains, reference in float64, errors relative to the tensor's max magnitude):
+forward and dgrad 2e-5, weight and bias gradients 5e-5 (reduction over up to 258 560 rows).
+"""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from cmoop_audio_processing_amd import EvalConfig, PopulationEvaluator, _lib, genes as G
+from cmoop_audio_processing_amd.session import NetSession
+from oracle import net as ON
+from oracle.net import conv_same
+
+pytestmark = pytest.mark.gpu
+
+ENV_MODE = os.environ.get("CMOOP_GEMM_MODE", "")
+if ENV_MODE:
+    pytest.skip("production-shape parity is defined for the exact-fp32 product path", allow_module_level=True)
+
+#: launch-path variants (cmoop_last_kernels / cmoop_profile_variant strings) exercised by a parity comparison in this
+#: module, filled as the tests run; the coverage test at the bottom reads it
+COVERED = set()
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+from _production_shapes import PRODUCTION_CONVS  # noqa: E402  (shared with the host-only coverage test)
+
+
+def _conv_case_ref(B, H, W, Cin, Cout, KS, stride, seed):
+    rs = np.random.RandomState(seed)
+    x = np.maximum(rs.randn(B, H, W, Cin), 0).astype(np.float32)          # a ReLU output, as in the nets
+    w = (rs.randn(Cout, KS, KS, Cin) / np.sqrt(KS * KS * Cin)).astype(np.float32)
+    b = (0.1 * rs.randn(Cout)).astype(np.float32)
+    OH, OW = -(-H // stride), -(-W // stride)
+    dy = rs.randn(B, OH, OW, Cout).astype(np.float32)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    bt = torch.from_numpy(b).double().requires_grad_(True)
+    y = conv_same(xt, wt, bt, stride)
+    y.backward(torch.from_numpy(dy).double().permute(0, 3, 1, 2))
+    ref = dict(y=y.detach().permute(0, 2, 3, 1).numpy(), dx=xt.grad.permute(0, 2, 3, 1).numpy() * (x > 0),
+               dw=wt.grad.numpy(), db=bt.grad.numpy())
+    return x, w, b, dy, ref
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,KS,stride", PRODUCTION_CONVS)
+def test_production_conv_shapes_through_the_trainer_launch_path(B, H, W, Cin, Cout, KS, stride):
+    L = _lib.lib()
+    x, w, b, dy, ref = _conv_case_ref(B, H, W, Cin, Cout, KS, stride, B + H + Cin + Cout + KS)
+    OH, OW = -(-H // stride), -(-W // stride)
+    M = B * OH * OW
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    # ---- forward (bias, no ReLU) with the BatchNorm statistics epilogue --------------------------------------------
+    y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
+    cs, cq, fused = np.zeros(Cout), np.zeros(Cout), C.c_int32(-1)
+    torch.cuda.synchronize()
+    _lib.check(L.cmoop_conv_fwd_trainer(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), B, H, W, Cin, Cout, KS, stride, 0,
+                                        _lib.ptr(cs), _lib.ptr(cq), C.byref(fused)))
+    names = _lib.last_kernels()
+    yh = y.cpu().numpy()
+    e_y = rel(yh, ref["y"])
+    # statistics: against float64 column sums of the values the kernel stored (what BatchNorm normalises)
+    y64 = yh.reshape(M, Cout).astype(np.float64)
+    e_s = float(np.abs(cs - y64.sum(0)).max() / np.abs(y64).sum(0).max())
+    e_q = float(np.abs(cq - (y64 ** 2).sum(0)).max() / (y64 ** 2).sum(0).max())
+    # ---- the same launch without statistics and with ReLU (the no-BatchNorm nets) -----------------------------------
+    y2 = torch.full_like(y, float("nan"))
+    torch.cuda.synchronize()
+    _lib.check(L.cmoop_conv_fwd_trainer(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y2), B, H, W, Cin, Cout, KS, stride, 1,
+                                        None, None, None))
+    names += _lib.last_kernels()
+    e_y2 = rel(y2.cpu().numpy(), np.maximum(ref["y"], 0))
+    # ---- backward: dgrad with the ReLU mask of the input, wgrad slabs + fixed-order sum, bias gradient ----------------
+    dx = torch.full((B, H, W, Cin), float("nan"), device="cuda")
+    dw = torch.full((Cout, KS, KS, Cin), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(L.cmoop_conv_bwd_trainer(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(dyd), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
+                                        B, H, W, Cin, Cout, KS, stride, 1))
+    names += _lib.last_kernels()
+    e_dx, e_dw, e_db = rel(dx.cpu().numpy(), ref["dx"]), rel(dw.cpu().numpy(), ref["dw"]), rel(db.cpu().numpy(), ref["db"])
+    print(f"{(B, H, W, Cin, Cout, KS, stride)}: y {e_y:.1e} relu-y {e_y2:.1e} stats {e_s:.1e}/{e_q:.1e} (fused={fused.value}) "
+          f"dx {e_dx:.1e} dw {e_dw:.1e} db {e_db:.1e}  {sorted(set(names))}")
+    assert e_y < 2e-5 and e_y2 < 2e-5 and e_dx < 2e-5 and e_dw < 5e-5 and e_db < 5e-5
+    assert fused.value in (0, 1) and e_s < 2e-6 and e_q < 2e-6
+    COVERED.update(names)
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(64, 512, 512, 1), (64, 256, 512, 1), (37, 64, 128, 1), (64, 10, 64, 0), (64, 35, 64, 0), (256, 512, 512, 1)])
+def test_dense_head_kernels(M, N, K, relu):
+    """dense.hip (MLP head, nsga_penalty.py:306-330): forward, dgrad with the ReLU mask, wgrad, bias gradient; K = 512 walks
+    the second trip of the kernels' 16-deep reduction loop per wave (never gradient-checked before)."""
+    L = _lib.lib()
+    rs = np.random.RandomState(M + N + K)
+    x = np.maximum(rs.randn(M, K), 0).astype(np.float32)
+    w = (rs.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    b = rs.randn(N).astype(np.float32)
+    dy = rs.randn(M, N).astype(np.float32)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    bt = torch.from_numpy(b).double().requires_grad_(True)
+    y = xt @ wt.t() + bt
+    if relu:
+        y = torch.relu(y)
+    y.backward(torch.from_numpy(dy).double())
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    yg = torch.full((M, N), float("nan"), device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(L.cmoop_dense_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(yg), M, N, K, relu))
+    assert rel(yg.cpu().numpy(), y.detach().numpy()) < 2e-5
+    # backward of the pre-activation: the trainer hands the dense kernels dY already masked by the layer's own ReLU
+    dyp = dy * (y.detach().numpy() > 0) if relu else dy
+    dx = torch.full((M, K), float("nan"), device="cuda")
+    dw = torch.full((N, K), float("nan"), device="cuda")
+    db = torch.full((N,), float("nan"), device="cuda")
+    dypd = dev(dyp.astype(np.float32))
+    torch.cuda.synchronize()
+    _lib.check(L.cmoop_dense_bwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(dypd), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), M, N, K, 1))
+    assert rel(dx.cpu().numpy(), xt.grad.numpy() * (x > 0)) < 2e-5
+    assert rel(dw.cpu().numpy(), wt.grad.numpy()) < 2e-5 and rel(db.cpu().numpy(), bt.grad.numpy()) < 2e-5
+
+
+def _per_tensor_err(gene, variant, classes, a, b):
+    from test_gpu_net import per_tensor_err
+    return per_tensor_err(gene, variant, classes, a, b)
+
+
+def _ocfg(cfg):
+    from test_gpu_net import ocfg
+    return ocfg(cfg)
+
+
+def _learnable_batch(n, T, F, classes, seed):
+    from test_gpu_net import make_data
+    return make_data(n, T, F, classes, seed)
+
+
+HEAVY_GENES = [
+    (64, 5, 1, 3, 4, 1),    # the heaviest gene of the bench's population class: 64 filters k5, BatchNorm, R = 3 (K = 512 head), dropout
+    (64, 3, 0, 3, 1, 0),    # 64 filters k3 without BatchNorm, R = 3
+    (32, 5, 0, 2, 3, 1),    # 32 filters k5 (the LDS-DMA tile), dropout
+    (64, 5, 1, 2, 2, 0),    # 64-filter BatchNorm gene, R = 2
+]
+
+
+@pytest.mark.parametrize("gene", HEAVY_GENES)
+def test_one_step_gradients_of_the_heavy_bench_genes_at_101x40_batch_64(gene):
+    """One optimiser step of a whole heavy candidate at the bench's shapes (101x40, batch 64, then a partial batch of 37):
+    per-tensor gradients HIP vs the float64 oracle, no worse than 5e-3 or 5x the fp32 oracle's own distance from float64
+    (with 16 M activations per layer a few ReLU / max-pool ties flip on either fp32 side: DESIGN section 2); then
+    inference from the updated weights.  Every MFMA launch of the two steps is sampled (profile_every = 1) and enters the
+    coverage set."""
+    classes, seed, T, F = 10, 21, 101, 40
+    cfg = EvalConfig(variant="A", classes=classes, batch=64, eval_batch=64, profile_every=1)
+    X, y = _learnable_batch(64, T, F, classes, 11)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    o32, o64 = ON.OracleNet(gene, _ocfg(cfg), seed), ON.OracleNet(gene, _ocfg(cfg), seed, dtype=torch.float64)
+    _lib.check(_lib.lib().cmoop_profile_reset())
+    with NetSession(gene, cfg, T, F, seed) as net:
+        assert np.array_equal(net.get_params(), o32.get_flat())
+        for b in (64, 37):
+            net.train_step(Xd, yd, None, row0=0, B=b)
+            o32.train_step(X[:b], y[:b])
+            o64.train_step(X[:b], y[:b])
+            e_hip = _per_tensor_err(gene, 0, classes, net.get_grads(), o64.grads_flat())
+            e_o32 = _per_tensor_err(gene, 0, classes, o32.grads_flat(), o64.grads_flat())
+            worst = max(e_hip, key=e_hip.get)
+            print(f"{gene} B={b}: worst HIP-vs-fp64 {worst} {e_hip[worst]:.2e} (fp32 oracle vs fp64 there: {e_o32[worst]:.2e}); "
+                  f"median HIP {np.median(list(e_hip.values())):.1e} / oracle {np.median(list(e_o32.values())):.1e}")
+            for name in e_hip:
+                assert e_hip[name] <= max(5e-3, 5.0 * e_o32[name]), (name, e_hip[name], e_o32[name])
+            # the first step's weights differ by Adam's sign-of-tiny-gradient flips: continue the second step from the GPU's state
+            st = net.get_state()
+            o32.set_state(st)
+            o64.set_state(st)
+        l_o, a_o, _ = o64.evaluate(X, y)
+        l_g, a_g, _ = net.evaluate(Xd, yd)
+        assert abs(l_g - l_o) < 1e-4 * max(1.0, abs(l_o)), (l_g, l_o)
+    COVERED.update(_lib.profile_variants())
+
+
+def test_fused_bn_pool_kernels_equal_the_unfused_pair_bit_for_bit(monkeypatch):
+    """bn_pool_fwd / bn_pool_bwd_* (BatchNorm-apply (+ReLU) + MaxPool SAME in one pass, the pool's backward folded into the
+    BatchNorm backward) claim bit-identical results to scale_shift + maxpool_fwd / maxpool_bwd + bn_bwd_*.
+    CMOOP_BN_POOL_UNFUSED=1 (read per net) plans the unfused pair: three steps (full, partial, full batch) of a BatchNorm
+    candidate of each topology must leave bit-identical parameters and gradients."""
+    T, F, classes, seed = 41, 20, 10, 5
+    rs = np.random.RandomState(3)
+    X, y = rs.randn(96, T, F).astype(np.float32), rs.randint(0, classes, 96).astype(np.int32)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    for variant, gene in (("A", (16, 3, 1, 2, 2, 1)), ("B", (32, 5, 1, 2, 1, 0))):
+        got = {}
+        for mode in ("fused", "unfused"):
+            if mode == "unfused":
+                monkeypatch.setenv("CMOOP_BN_POOL_UNFUSED", "1")
+            else:
+                monkeypatch.delenv("CMOOP_BN_POOL_UNFUSED", raising=False)
+            cfg = EvalConfig(variant=variant, classes=classes, batch=32, eval_batch=32)
+            with NetSession(gene, cfg, T, F, seed) as net:
+                for step, b in enumerate((32, 19, 32)):
+                    net.train_step(Xd, yd, None, row0=32 * step, B=b)
+                loss, acc, preds = net.evaluate(Xd, yd)
+                got[mode] = (np.array(net.get_params()), np.array(net.get_grads()), loss, preds.cpu().numpy())
+        monkeypatch.delenv("CMOOP_BN_POOL_UNFUSED", raising=False)
+        a, b = got["fused"], got["unfused"]
+        assert np.isfinite(a[0]).all()
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        assert a[2] == b[2] and np.array_equal(a[3], b[3])
+
+
+def test_a_corrupt_shuffle_index_cannot_address_outside_the_resident_tensor():
+    """the first-layer kernels and the loss gather rows through idx without a bound; the only producer is the
+    device permutation, but a poisoned buffer would fault the GPU.  With the row count set (the trainer always sets it),
+    indices are clamped into [0, n_rows): a step on garbage indices completes with finite gradients."""
+    T, F, classes = 21, 12, 10
+    rs = np.random.RandomState(0)
+    X, y = rs.randn(40, T, F).astype(np.float32), rs.randint(0, classes, 40).astype(np.int32)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    bad = torch.tensor([2 ** 31 - 1, -5, 10 ** 9, -2 ** 31, 39, 40, 41, 0] * 4, dtype=torch.int32, device="cuda")
+    with NetSession((16, 3, 1, 1, 1, 0), EvalConfig(batch=32, eval_batch=32), T, F, 1) as net:
+        net.set_gather_rows(40)
+        net.train_step(Xd, yd, bad, row0=0, B=32)
+        assert np.isfinite(net.get_grads()).all()
+        # clamped rows: the step equals the step on the clamped indices
+        g_bad = np.array(net.get_grads())
+    with NetSession((16, 3, 1, 1, 1, 0), EvalConfig(batch=32, eval_batch=32), T, F, 1) as net:
+        net.train_step(Xd, yd, torch.clamp(bad.long(), 0, 39).to(torch.int32), row0=0, B=32)
+        assert np.array_equal(g_bad.view(np.uint32), np.array(net.get_grads()).view(np.uint32))
+
+
+def test_every_launch_variant_of_the_pop40_job_is_covered_by_a_parity_case():
+    """Coverage assertion: run the bench's population (40 genes of random.Random(0), topology A,
+    101x40, batch 64, eval_batch 256) with EVERY MFMA launch sampled, collect the launch-path variants it used --
+    instantiation <BM, BN, BK, WM, MODE> / <BCO, BKI> plus split-K / statistics-epilogue / row-table / slab flags -- and
+    fail if one of them was not exercised by a parity comparison above (kernel-level production shapes or the heavy-gene
+    gradient checks).  A new tile choice in launch_igemm_fwd / _wgrad therefore needs a parity case before it ships."""
+    if not COVERED:
+        pytest.skip("run together with the parity cases of this module (they fill the coverage set)")
+    from test_gpu_net import make_split
+    classes = 10
+    rng = random.Random(0)
+    pop = [G.random_hparams(rng) for _ in range(40)]
+    Xtr, ytr, Xva, yva = make_split(128, 256, 101, 40, classes, 9, noise=0.3)
+    cfg = EvalConfig.preset("nsga_penalty", epochs=1, batch=64, eval_batch=256, seed=0, early_stop=False, n_slots=8, profile_every=1)
+    _lib.check(_lib.lib().cmoop_profile_reset())
+    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, cfg)
+    ev.compute_objectives_and_constraints(pop)
+    used = set(_lib.profile_variants())
+    names = {n for n, *_ in _lib.profile_entries()}
+    assert len(names) >= 12, names
+    missing = sorted(used - COVERED)
+    print(f"{len(used)} launch-path variants in the pop-40 job, {len(COVERED)} covered by parity cases")
+    assert not missing, f"launch-path variants of the pop-40 job without a parity case: {missing}"

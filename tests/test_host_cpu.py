@@ -21,7 +21,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(L, n), n
-    assert L.cmoop_abi_version() == 2
+    assert L.cmoop_abi_version() == 3
 
 
 def test_abi_host_only_closed_forms_match_python():
@@ -273,3 +273,56 @@ def test_shape_time_share_tool_walks_the_same_layers_as_the_model():
     # spatial sizes: SAME pools halve with ceil (101x40 -> 51x20 -> 26x10 -> 13x5)
     assert [(h, w) for (h, w, *_rest) in mod.conv_shapes((16, 3, 0, 3, 1, 0))] == \
            [(101, 40)] + [(51, 20)] * 3 + [(26, 10)] * 3 + [(13, 5)] * 3
+
+
+def test_every_launch_variant_of_every_gene_has_a_gpu_parity_case():
+    """the kernels that carry the benchmark must not run uncompared.  cmoop_conv_launch_plan (host-only
+    twin of the launchers' tile / split-K / operand-path choice) gives the launch-path variant the trainer uses for a conv
+    layer; enumerate forward (with / without the BatchNorm statistics epilogue), dgrad and wgrad of EVERY conv layer of
+    EVERY gene of the search space, both topologies, at the reference's batch (64), a partial last batch (37) and the
+    inference batch (256) on 101x40 features -- each variant must be launched by one of the production-shape parity cases
+    of tests/test_gpu_production_shapes.py (same plan function applied to its shape list)."""
+    import itertools
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import launch_variants as LV
+    from _production_shapes import PRODUCTION_CONVS
+    covered = set()
+    for (B, H, W, Ci, Co, KS, st) in PRODUCTION_CONVS:
+        covered |= {LV.plan(0, B, H, W, Ci, Co, KS, st, 1), LV.plan(0, B, H, W, Ci, Co, KS, st, 0),
+                    LV.plan(1, B, H, W, Ci, Co, KS, st), LV.plan(2, B, H, W, Ci, Co, KS, st)}
+    genes = list(itertools.product((16, 32, 64), (3, 5), (0, 1), (1, 2, 3), (1,), (0,)))     # fc / dropout genes add no conv shape
+    for variant in (0, 1):
+        used = LV.variants_of(genes, variant, 101, 40)
+        missing = {k: sorted(v)[:3] for k, v in used.items() if k not in covered}
+        assert not missing, f"launch-path variants without a GPU parity case (topology {variant}): {missing}"
+    assert len(covered) >= 30
+    # the names are the ones rocprofv3 prints: the LDS-DMA instantiation carries MODE = 1
+    assert "igemm_fwd_kernel<128, 32, 32, 4, 1>+stats+tab" in covered and "igemm_wgrad_kernel<128, 128>+tab+slabs" in covered
+
+
+def test_32bit_byte_offset_guard_refuses_oversized_plans():
+    """ADVICE r2 / VERDICT r2 item 9: buffer descriptors, row tables and per-row offsets hold BYTES in 32 bits, so every
+    tensor a GEMM launch addresses must stay below 2^29 elements; beyond that the hardware range check would return
+    zeros silently.  cmoop_plan_check (and net creation / the population calls) refuse instead.  All genes x {101x40,
+    128x128} x {batch 64, eval_batch 256, 1024}: the reference's own sizes pass, the oversized ones raise."""
+    import itertools
+    L = _lib.lib()
+    refused = 0
+    for gene in itertools.product((16, 32, 64), (3, 5), (0, 1), (1, 2, 3), (1, 4), (0, 1)):
+        g = (C.c_int32 * 6)(*gene)
+        for variant in (0, 1):
+            for (T, F) in ((101, 40), (128, 128)):
+                for B in (64, 256, 1024):
+                    biggest = B * T * F * gene[0]                     # the first conv's output is the largest tensor of a candidate
+                    rc = L.cmoop_plan_check(g, variant, T, F, B)
+                    if biggest < 2 ** 29:
+                        assert rc == 0, (gene, variant, T, F, B, L.cmoop_last_error())
+                    else:
+                        assert rc != 0 and b"2^29" in L.cmoop_last_error(), (gene, variant, T, F, B)
+                        refused += 1
+    assert refused > 0                                                 # 128x128 x 64 filters x eval_batch 1024 = 2^30 elements
+    # a shape just above the limit at the layer level (host-only launch plan uses the same guard)
+    buf = C.create_string_buffer(200)
+    assert L.cmoop_conv_launch_plan(0, 2 ** 13, 256, 256, 16, 16, 3, 1, 0, buf, 200) != 0      # 2^13 * 2^16 * 16 = 2^33
+    assert L.cmoop_conv_launch_plan(0, 64, 101, 40, 16, 16, 3, 1, 0, buf, 200) == 0

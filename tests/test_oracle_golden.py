@@ -223,3 +223,43 @@ def test_oracle_mfcc_is_the_orthonormal_dct_of_log_mel():
     assert np.abs(lm @ basis.T - full).max() < 1e-10
     assert np.allclose((full ** 2).sum(-1), (lm ** 2).sum(-1), rtol=1e-12)
     assert np.array_equal(part, full[..., :13])
+
+
+def test_prepare_dataset_matches_the_reference_executed_here(golden_dir, tmp_path):
+    """load_data + prepare_dataset of nsga_penalty.py:57-155 (StandardScaler re-fit on every split: quirk
+    Q1) and mobo_penalty.py:32-82 (fit on train only) are NumPy + scikit-learn and were EXECUTED in the build container
+    (tests/golden/make_golden.py, AST-extracted) on six small .npy files; the fixture holds inputs and outputs.  Pinned
+    against it: the loader (datasets.load_npy_splits: return order, labels (N,) -> (N,1)) and the oracle's scaler
+    (oracle.frontend.scaler_fit / scaler_transform) composed per mode, incl. a zero-variance feature (scale 1).
+    Tolerance: float64 files 1e-12; float32 files 2e-6 absolute (the reference then subtracts / divides in float32,
+    the oracle in float64 and rounds once)."""
+    from cmoop_audio_processing_amd import datasets as D
+    from oracle import frontend as ofe
+    fx = json.load(open(os.path.join(golden_dir, "prepare_dataset_golden.json")))
+    assert len(fx["cases"]) == 2
+    for case in fx["cases"]:
+        dt = np.dtype(case["dtype"])
+        d = tmp_path / case["dtype"]
+        d.mkdir()
+        for k in ("train", "val", "test"):
+            np.save(d / f"X_{k}.npy", np.asarray(case["inputs"][f"X_{k}"], dtype=dt))
+            np.save(d / f"y_{k}.npy", np.asarray(case["inputs"][f"y_{k}"], dtype=np.int64))
+        X_train, X_test, X_val, y_train, y_test, y_val = D.load_npy_splits(str(d))          # reference return order (:83)
+        tol = 1e-12 if dt == np.float64 else 2e-6
+        for mode in ("refit", "train_only"):
+            ref = case[mode]
+            assert list(y_train.shape) == ref["y_shape"] and y_train.tolist() == ref["y_train"]
+            assert y_val.tolist() == ref["y_val"] and y_test.tolist() == ref["y_test"]
+            assert ref["X_shape"] == [len(X_train), case["T"], case["F"], 1] and ref["X_dtype"] == case["dtype"]
+            m0, s0 = ofe.scaler_fit(X_train)
+            for name, X in (("X_train", X_train), ("X_val", X_val), ("X_test", X_test)):
+                m, s = (m0, s0) if (mode == "train_only" or name == "X_train") else ofe.scaler_fit(X)
+                got = ((np.asarray(X, np.float64) - m) / s)
+                want = np.asarray(ref[name], np.float64)[..., 0]
+                assert np.abs(got - want).max() <= tol, (case["dtype"], mode, name, np.abs(got - want).max())
+                assert np.abs(ofe.scaler_transform(X, m, s) - want).max() <= 2e-6
+            # the constant feature: StandardScaler sets its scale to 1, the value becomes exactly 0
+            assert np.abs(np.asarray(ref["X_train"])[:, :, 3, 0]).max() == 0.0 and s0[3] == 1.0
+        # Q1 is visible in the fixture: the two modes agree on train and differ on validation
+        assert np.allclose(case["refit"]["X_train"], case["train_only"]["X_train"])
+        assert np.abs(np.asarray(case["refit"]["X_val"]) - np.asarray(case["train_only"]["X_val"])).max() > 0.1
