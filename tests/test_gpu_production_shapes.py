@@ -163,14 +163,38 @@ HEAVY_GENES = [
 ]
 
 
+def _rel_l2_per_tensor(gene, variant, classes, a, b):
+    """||a - b|| / ||b|| of each canonical tensor (conv biases in front of a train-mode BatchNorm excluded: their gradient is
+    analytically zero)."""
+    out, off = {}, 0
+    tensors = G.param_tensors(gene, variant, classes)
+    for i, (name, shape, role) in enumerate(tensors):
+        n = int(np.prod(shape))
+        dead = role == "bias" and i + 1 < len(tensors) and tensors[i + 1][2] == "gamma" and variant == 0
+        if not dead and role in ("kernel", "bias", "gamma", "beta"):
+            ra, rb = a[off:off + n].astype(np.float64), b[off:off + n].astype(np.float64)
+            out[name] = float(np.linalg.norm(ra - rb) / max(np.linalg.norm(rb), 1e-30))
+        off += n
+    return out
+
+
 @pytest.mark.parametrize("gene", HEAVY_GENES)
 def test_one_step_gradients_of_the_heavy_bench_genes_at_101x40_batch_64(gene):
     """One optimiser step of a whole heavy candidate at the bench's shapes (101x40, batch 64, then a partial batch of 37):
-    per-tensor gradients HIP vs the float64 oracle, no worse than 5e-3 or 5x the fp32 oracle's own distance from float64
-    (with 16 M activations per layer a few ReLU / max-pool ties flip on either fp32 side: DESIGN section 2); then
-    inference from the updated weights.  Every MFMA launch of the two steps is sampled (profile_every = 1) and enters the
-    coverage set."""
+    per-tensor gradients HIP vs the FLOAT64 oracle; then inference from the updated weights.  Every MFMA launch of the two
+    steps is sampled (profile_every = 1) and enters the coverage set.
+
+    What bounds such a comparison (measured on the CPU): with ~16 M activations per layer a few max-pool /
+    ReLU decisions sit within fp32 rounding of a tie, and ONE flipped decision in a late low-resolution layer perturbs
+    every upstream gradient broadly (a kernel gradient is a sum of ~10^4 cancelling terms, so one re-routed term is ~1e-2
+    of it; BatchNorm's backward couples all positions).  The fp32 oracle itself lands 1e-7 ... 8e-3 (max) away from the
+    float64 one per tensor, and its two CPU conv algorithms disagree on WHICH tensors are hit (res1_conv1/kernel: 1.2e-4
+    vs 5.0e-3).  Either fp32 side draws these flips independently, so the gate is: max-abs error per tensor <= 5x the fp32
+    oracle's own or a floor (5e-3 without BatchNorm, 3e-2 with), AND relative L2 error per tensor <= 2e-3 / 1e-2 -- a
+    corrupt slab, a missed K chunk or a wrong tile are broad O(1e-1..1) errors; kernel arithmetic is gated at 2e-5 by the
+    kernel-level cases above."""
     classes, seed, T, F = 10, 21, 101, 40
+    floor, l_gate = (3e-2, 1e-2) if gene[2] else (5e-3, 2e-3)
     cfg = EvalConfig(variant="A", classes=classes, batch=64, eval_batch=64, profile_every=1)
     X, y = _learnable_batch(64, T, F, classes, 11)
     Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
@@ -182,13 +206,18 @@ def test_one_step_gradients_of_the_heavy_bench_genes_at_101x40_batch_64(gene):
             net.train_step(Xd, yd, None, row0=0, B=b)
             o32.train_step(X[:b], y[:b])
             o64.train_step(X[:b], y[:b])
-            e_hip = _per_tensor_err(gene, 0, classes, net.get_grads(), o64.grads_flat())
-            e_o32 = _per_tensor_err(gene, 0, classes, o32.grads_flat(), o64.grads_flat())
-            worst = max(e_hip, key=e_hip.get)
-            print(f"{gene} B={b}: worst HIP-vs-fp64 {worst} {e_hip[worst]:.2e} (fp32 oracle vs fp64 there: {e_o32[worst]:.2e}); "
-                  f"median HIP {np.median(list(e_hip.values())):.1e} / oracle {np.median(list(e_o32.values())):.1e}")
+            g_hip, g_32, g_64 = net.get_grads(), o32.grads_flat(), o64.grads_flat()
+            e_hip = _per_tensor_err(gene, 0, classes, g_hip, g_64)
+            e_o32 = _per_tensor_err(gene, 0, classes, g_32, g_64)
+            l_hip, l_o32 = _rel_l2_per_tensor(gene, 0, classes, g_hip, g_64), _rel_l2_per_tensor(gene, 0, classes, g_32, g_64)
+            worst, wl = max(e_hip, key=e_hip.get), max(l_hip, key=l_hip.get)
+            print(f"{gene} B={b}: worst max-abs HIP-vs-fp64 {worst} {e_hip[worst]:.2e} (fp32 oracle there {e_o32[worst]:.2e}, its own worst "
+                  f"{max(e_o32.values()):.2e}); worst rel-L2 {wl} {l_hip[wl]:.2e} (oracle's worst {max(l_o32.values()):.2e}); "
+                  f"median max-abs HIP {np.median(list(e_hip.values())):.1e} / oracle {np.median(list(e_o32.values())):.1e}")
             for name in e_hip:
-                assert e_hip[name] <= max(5e-3, 5.0 * e_o32[name]), (name, e_hip[name], e_o32[name])
+                assert e_hip[name] <= max(floor, 5.0 * e_o32[name]), (name, e_hip[name], e_o32[name])
+            for name in l_hip:
+                assert l_hip[name] <= max(l_gate, 5.0 * l_o32[name]), (name, l_hip[name], l_o32[name])
             # the first step's weights differ by Adam's sign-of-tiny-gradient flips: continue the second step from the GPU's state
             st = net.get_state()
             o32.set_state(st)
