@@ -329,13 +329,24 @@ def _es_replay(cfg, val_loss_history):
     return len(val_loss_history), es.best_epoch
 
 
-def _bn_stat_deviation(tensors, pa, pb):
-    """largest |moving statistic a - b| relative to that tensor's largest entry (floor 1e-3)"""
-    off, worst = 0, 0.0
+def _bn_stat_deviation(tensors, pa, pb, conv_bias_gauge=False, steps=0):
+    """largest |moving statistic a - b| relative to that tensor's largest entry (floor 1e-3).
+
+    conv_bias_gauge (topology A, where BatchNorm directly follows a conv): that conv's bias has an analytically ZERO
+    gradient (BatchNorm removes it), so under Adam it performs an implementation-specific random walk driven by rounding
+    noise, and moving_mean -- an average of batch means that contain the bias -- lags behind it.  For those moving_mean
+    tensors the part of the difference that the two runs' bias difference explains (<= momentum-weight 0.01 per step x
+    `steps` x 2 x the final bias difference) is not counted; moving_var is shift-invariant and always counted in full."""
+    off, worst, bias = 0, 0.0, None
     for name, shape, role in tensors:
         n = int(np.prod(shape))
+        if role == "bias":
+            bias = (off, n)
         if role in ("moving_mean", "moving_var"):
-            worst = max(worst, float(np.abs(pa[off:off + n] - pb[off:off + n]).max()) / max(float(np.abs(pb[off:off + n]).max()), 1e-3))
+            d = float(np.abs(pa[off:off + n] - pb[off:off + n]).max())
+            if role == "moving_mean" and conv_bias_gauge and bias is not None and bias[1] == n:
+                d = max(0.0, d - 0.02 * steps * float(np.abs(pa[bias[0]:bias[0] + n] - pb[bias[0]:bias[0] + n]).max()))
+            worst = max(worst, d / max(float(np.abs(pb[off:off + n]).max()), 1e-3))
         off += n
     return worst
 
@@ -417,7 +428,7 @@ def resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=None,
             assert l_g == hist_l[e] and a_g == hist_a[e], f"epoch {e}: the replayed GPU run left the product's trajectory ({l_g} vs {hist_l[e]})"
             d_loss = abs(l_g - l_o) / max(1.0, abs(l_o))
             d_pred = _decisive_differences(p_g.cpu().numpy(), p_o, probs(onet))
-            d_stat = _bn_stat_deviation(tensors, net.get_params(), onet.get_flat())
+            d_stat = _bn_stat_deviation(tensors, net.get_params(), onet.get_flat(), conv_bias_gauge=(v == 0), steps=-(-len(Xtr) // cfg.batch))
             tight = d_loss <= loss_tol and d_pred <= pred_tol and d_stat <= stat_tol
             if not tight:
                 # the oracle's own reproducibility over THIS epoch from THIS state: other conv algorithm, and float64
@@ -434,7 +445,8 @@ def resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=None,
                     twins.append((tw,) + tuple(tw.evaluate(Xva, yva)))
                 s_loss = max(abs(l_t - l_o) / max(1.0, abs(l_o)) for _, l_t, _, _ in twins)
                 s_pred = max(_decisive_differences(p_t, p_o, probs(onet)) for _, _, _, p_t in twins)
-                s_stat = max(_bn_stat_deviation(tensors, t_.get_flat().astype(np.float32), onet.get_flat()) for t_, _, _, _ in twins)
+                s_stat = max(_bn_stat_deviation(tensors, t_.get_flat().astype(np.float32), onet.get_flat(), conv_bias_gauge=(v == 0),
+                                                 steps=-(-len(Xtr) // cfg.batch)) for t_, _, _, _ in twins)
                 band_epochs.append((e, f"loss {d_loss:.1e}/{s_loss:.1e} preds {d_pred}/{s_pred} stats {d_stat:.1e}/{s_stat:.1e}"))
                 assert d_loss <= max(loss_tol, 5.0 * s_loss) and d_pred <= max(pred_tol, 2 * s_pred + 1) and d_stat <= max(stat_tol, 5.0 * s_stat), \
                     f"{tag} {gene} epoch {e}: GPU vs oracle / oracle vs its own twins: {band_epochs[-1][1]}"
