@@ -337,7 +337,7 @@ def _bn_stat_deviation(tensors, pa, pb, conv_bias_gauge=False, steps=0, lr=1e-3)
     implementation-specific random walk of up to ~lr per step driven by rounding noise -- in Keras as much as here -- and
     moving_mean, an average of batch means that CONTAIN the bias, carries that walk with a lag.  Those moving_mean tensors
     are therefore not comparable between any two implementations beyond the walk's reach; they are checked against that
-    reach only (0.01 momentum weight x sum over the epoch's steps of 2 lr t) and, functionally, through the inference pass
+    reach only (0.01 momentum weight x sum over the epoch's steps of 2 x 3.17 lr t) and, functionally, through the inference pass
     they feed (validation loss / predictions, gated tightly by the caller).  moving_var is shift-invariant and every other
     moving_mean (topology B: BatchNorm after the ReLU) is compared in full."""
     off, worst, bias = 0, 0.0, None
@@ -348,7 +348,8 @@ def _bn_stat_deviation(tensors, pa, pb, conv_bias_gauge=False, steps=0, lr=1e-3)
         if role in ("moving_mean", "moving_var"):
             d = float(np.abs(pa[off:off + n] - pb[off:off + n]).max())
             if role == "moving_mean" and conv_bias_gauge and bias is not None and bias[1] == n:
-                assert d <= 0.01 * 2.0 * lr * steps * (steps + 1) / 2 + 1e-5 * max(float(np.abs(pb[off:off + n]).max()), 1e-3), (name, d)
+                # Adam's largest possible step is lr (1 - beta1) / sqrt(1 - beta2) = 3.16 lr (a gradient appearing after zeros)
+                assert d <= 0.01 * 2.0 * 3.17 * lr * steps * (steps + 1) / 2 + 1e-5 * max(float(np.abs(pb[off:off + n]).max()), 1e-3), (name, d)
             else:
                 worst = max(worst, d / max(float(np.abs(pb[off:off + n]).max()), 1e-3))
         off += n
@@ -363,7 +364,7 @@ def _decisive_differences(pred_a, pred_b, probs_b, margin=2e-3):
     return int(((np.asarray(pred_a) != np.asarray(pred_b)) & decisive).sum())
 
 
-def resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=None, loss_tol=1e-4, pred_tol=1, stat_tol=1e-5, tag=""):
+def resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=None, loss_tol=1e-4, pred_tol=1, stat_tol=5e-5, tag=""):
     """Tight end-to-end parity of the FULL early-stopped protocol without comparing two long chaotic fp32 trajectories at
     their ends: the GPU and the oracle are RE-SYNCHRONISED at every epoch boundary.
 
@@ -481,7 +482,7 @@ RESYNC_PROTOCOLS = [
 @pytest.mark.parametrize("preset,gene", RESYNC_PROTOCOLS)
 def test_full_protocol_resynchronised_every_epoch(preset, gene):
     """The full early-stopped protocol of each reference script (25 epochs, patience 2, ~100-150 optimiser steps) gated
-    TIGHTLY at every epoch -- val loss 1e-4, <= 1 decisive prediction, moving statistics 1e-5, early-stopping decisions
+    TIGHTLY at every epoch -- val loss 1e-4, <= 1 decisive prediction, moving statistics 5e-5, early-stopping decisions
     exact -- by re-synchronising the oracle with the GPU at each epoch boundary (resynchronised_fit_check); an epoch that
     misses a tight gate must lie within 5x of the oracle's own one-epoch reproducibility from the same state, and at most
     a third of a run's epochs may need that.  This replaces round 2's end-of-run statistical band for the BatchNorm +
@@ -660,7 +661,7 @@ def test_sa_nsga2_35_classes_gpu_search_replayed_on_the_oracle_config2():
     pop 8 / gen 2 -> 8 + 2 * 1 true evaluations.  Round 2 ran a second, independent search on the oracle and compared
     hypervolumes after the two had diverged (one flipped prediction re-routes the Kriging infill): a 0.5-2.0x gate.  Now the
     GPU drives and the oracle REPLAYS: each of the 10 candidates the search evaluated is checked at every epoch of its
-    early-stopped run (val loss 1e-4, <= 1 prediction, moving statistics 1e-5, early-stopping decisions exact), and its
+    early-stopped run (val loss 1e-4, <= 1 decisive prediction, moving statistics 5e-5, early-stopping decisions exact), and its
     objectives as the search saw them are reproduced bit for bit -- so the search consumed correct numbers, whatever
     route it took.  (The host loop itself is pinned by tests/golden/surrogate_golden.json.)"""
     from cmoop_audio_processing_amd import nsga, surrogate as S
@@ -836,7 +837,7 @@ def test_hard_synthetic_set_search_replayed_epoch_by_epoch():
     Round 2 showed that end-of-run comparisons are a lottery on this task for ANY two implementations (the fp32 and float64
     oracles end 5-14 accuracy points apart on single candidates; a 25 % hypervolume gate was all that held).  Instead the
     GPU drives the search and each of its 12 true evaluations is replayed on the oracle with a re-synchronisation at every
-    epoch boundary (resynchronised_fit_check): val loss within 1e-4, <= 1 prediction, moving statistics 1e-5 per epoch,
+    epoch boundary (resynchronised_fit_check): val loss within 1e-4, <= 1 decisive prediction, moving statistics 5e-5 per epoch,
     early-stopping decisions and read-outs exact, the search's objectives reproduced bit for bit."""
     import bench
     from cmoop_audio_processing_amd import frontend, nsga
