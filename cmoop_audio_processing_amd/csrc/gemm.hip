@@ -858,7 +858,10 @@ static inline int resident_wgs_128(int bn) { return 256 * (bn >= 64 ? 2 : 3); }
 static size_t balanced_slab_floats(int M, int N, int K, int bk, int bn, int* wgs_out) {
     if (bk != 32) return 0;
     const long tiles = (long)cdiv(M, 128) * cdiv(N, bn);
-    const int chunks = cdiv(K, 32), W = resident_wgs_128(bn);
+    // CMOOP_BALANCED_MULT (1, 2, 4): workgroups of a balanced launch in multiples of the co-resident count -- more, shorter
+    // workgroups interleave better with the other candidates' kernels, at the price of more partial-tile slots
+    static const int mult = [] { const char* v = std::getenv("CMOOP_BALANCED_MULT"); const int m = v ? std::atoi(v) : 1; return (m == 2 || m == 4) ? m : 1; }();
+    const int chunks = cdiv(K, 32), W = resident_wgs_128(bn) * mult;
     if (tiles > W || tiles * chunks < 8l * W) return 0;          // at most two pieces per workgroup; at least 8 chunks each
     const int L = (int)((tiles * chunks + W - 1) / W);
     if (wgs_out) *wgs_out = W;
@@ -874,11 +877,13 @@ static void pick_tile(int M, int N, int K, int bk, size_t ws_floats, int* bm, in
     const long fill = std::max(32l, (long)(384 * par_scale()));
     if (blocks >= fill) { *bm = 128; *bn = bn_big; return; }
     const int nchunks = cdiv(K, bk);
-    // Balanced K partition: +11..26 % on the 26x10 / 13x5 layer shapes with the launch ALONE on the chip, but 1.3 % SLOWER
-    // whole-job (2 094 vs 2 121 evals/h): with eight candidates in flight the empty slots of a ragged wave are filled by
-    // the other streams' workgroups anyway, and 512 long workgroups balance worse against that traffic than 1 820 short
-    // ones.  Kept for single-stream use (CMOOP_BALANCED=1, e.g. one candidate per GPU); off by default.
-    static const bool balanced_on = [] { const char* v = std::getenv("CMOOP_BALANCED"); return v && v[0] == '1'; }();
+    // Balanced K partition (default since round 3; CMOOP_BALANCED=0 restores the uniform split): +11..26 % on the 26x10 /
+    // 13x5 layer shapes with the launch alone on the chip (256->256 k5 @26x10: 99 -> 127 TFLOP/s; the heaviest bench
+    // candidate alone 8.46 -> 7.99 ms per step).  Round 2 measured it 1.3 % SLOWER whole-job with eight candidates in flight
+    // and kept it opt-in; re-measured in round 3 on the same box, same minute: 2 173.6 vs 2 167.3 evals/h (+0.3 %, noise
+    // level) -- no longer a loss, and the lone / tail case is a clear win.  More, shorter workgroups (CMOOP_BALANCED_MULT
+    // 2 / 4: 1 024 / 2 048 instead of 512) lose both alone (8.07 / 8.22 ms) and in the job (2 165.9 / 2 146.3).
+    static const bool balanced_on = [] { const char* v = std::getenv("CMOOP_BALANCED"); return !(v && v[0] == '0'); }();
     if (balanced_on) {
         int W = 0;
         const size_t need = balanced_slab_floats(M, N, K, bk, bn_big, &W);

@@ -35,4 +35,5 @@ PRODUCTION_CONVS = [
     (37, 51, 20, 32, 32, 3, 1),
     (64, 26, 10, 32, 64, 3, 1),
     (37, 26, 10, 32, 64, 3, 1),
+    (37, 26, 10, 64, 64, 3, 1),      # too few K chunks for the balanced partition: the uniform split-K path of the 128x64 tile
 ]
