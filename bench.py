@@ -325,6 +325,7 @@ def main(argv=None, t_origin=None):
                          "EarlyStopping(val_loss, patience 5), <= 300 epochs (nsga_penalty.py:159-161,377-384) on the hard synthetic set; "
                          "reports the epochs distribution; one generation, builder-side (minutes to tens of minutes)")
     ap.add_argument("--lone-steps", type=int, default=40, help="train steps of the lone-heaviest-candidate roofline leg (0: skip)")
+    ap.add_argument("--lone-gene", default="", help="f,k,bn,R,fc,dr: gene of the lone-candidate leg (default: the heaviest of the population)")
     ap.add_argument("--lone-only", action="store_true",
                     help="setup + the lone-candidate leg only (no population run): the command to put under rocprofv3 --kernel-trace --stats")
     ap.add_argument("--variant", default="A")
@@ -501,6 +502,9 @@ def main(argv=None, t_origin=None):
         from cmoop_audio_processing_amd.session import NetSession
         fl = [G.fwd_flops_per_sample(g, variant, args.classes, T, F) for g in genes]
         gene = genes[int(np.argmax(fl))]
+        if args.lone_gene:
+            gene = tuple(int(v) for v in args.lone_gene.split(","))
+            fl = [G.fwd_flops_per_sample(gene, variant, args.classes, T, F)]
         lcfg = _replace(cfg, profile_every=1, n_slots=1, early_stop=False, epochs=1)
         rows = min(n_tr // cfg.batch, n_steps + 3) * cfg.batch
         with NetSession(gene, lcfg, T, F, args.seed) as net:

@@ -875,6 +875,9 @@ static void pick_tile(int M, int N, int K, int bk, size_t ws_floats, int* bm, in
     *balanced_wgs = 0;
     long blocks = (long)cdiv(M, 128) * cdiv(N, bn_big);
     const long fill = std::max(32l, (long)(384 * par_scale()));
+    // (Measured twice, not adopted: 256 x 64 tiles with 16-deep chunks for the 64-column layers at 101x40 -- every wave owns
+    // 64 x 64 like the 128 x 128 kernel, two workgroups per CU: forward / dgrad 111.9 / 111.7 vs 122.6 / 122.6 TFLOP/s on
+    // 64->64 k5, 95.8 / 97.7 vs 104.9 / 113.9 on k3; 2 155 vs 2 179 evals/h in the job.  Round 2's 32-deep form: 109.6 vs 118.5.)
     if (blocks >= fill) { *bm = 128; *bn = bn_big; return; }
     const int nchunks = cdiv(K, bk);
     // Balanced K partition (default since round 3; CMOOP_BALANCED=0 restores the uniform split): +11..26 % on the 26x10 /
@@ -993,7 +996,6 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
         else if (bk32_tile) launch_fwd_t<BM_, BN_, 32, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);   \
         else launch_fwd_t<BM_, BN_, 16, WM_>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, 0, rowtab, tab_rows);        \
     } while (0)
-    // (Measured, not adopted: 256x64 tiles for the 64-column layers at 101x40 -- 109.6 vs 118.5 TFLOP/s forward.)
     if (bm == 128) {
         if (bn == 128) CMOOP_FWD(128, 128, 2);
         else if (bn == 64) CMOOP_FWD(128, 64, 4);
