@@ -366,11 +366,12 @@ def _decisive_differences(pred_a, pred_b, probs_b, margin=2e-3):
 
 def _stepwise_epoch_check(gene, cfg, seed, epoch, state, Xtr, ytr, Xtr_d, ytr_d, tensors, v, tag):
     """One epoch replayed from `state` on a fresh GPU net with the fp32 oracle re-synchronised before EVERY optimiser step
-    (the finest horizon there is: nothing can be amplified).  Per step: training loss within 1e-5 (relative, floor 1),
-    BatchNorm moving statistics within 1e-5, per-tensor gradients within 1e-4 of the tensor's max -- except on the few
-    tensors a max-pool / ReLU tie that rounded the other way touches (sparse spikes up to a few 1e-2, seen on either
-    fp32 side about once in five steps: profiles/r03_adam_first_step_tie_flips.txt): at most a quarter of the tensors, none
-    beyond 1e-1."""
+    (the finest horizon there is: nothing can be amplified).  Per step: training loss within 1e-5 (relative, floor 1) and
+    BatchNorm moving statistics within 1e-5 -- the forward pass has no discrete decisions that matter -- and per-tensor
+    gradients within 1e-4 of the tensor's max on the steps without a tie flip.  A max-pool / ReLU tie that rounds the
+    other way in the backward pass (seen on either fp32 side about once in five steps: profiles/
+    r03_adam_first_step_tie_flips.txt) re-routes one gradient term in a late layer and perturbs EVERY upstream tensor by
+    1e-4 ... a few 1e-2: such steps are allowed up to 1e-1, but at least half of the epoch's steps must be clean."""
     from cmoop_audio_processing_amd.session import epoch_permutation
     T, F = int(Xtr.shape[1]), int(Xtr.shape[2])
     perm = epoch_permutation(seed, epoch, len(Xtr)) if cfg.shuffle else np.arange(len(Xtr), dtype=np.int32)
@@ -379,6 +380,7 @@ def _stepwise_epoch_check(gene, cfg, seed, epoch, state, Xtr, ytr, Xtr_d, ytr_d,
         net.set_state(state)
         net.train_metrics()
         onet = ON.OracleNet(gene, ocfg(cfg), seed)
+        n_steps = n_clean = 0
         for s0 in range(0, len(Xtr), cfg.batch):
             b = min(cfg.batch, len(Xtr) - s0)
             onet.set_state(net.get_state())
@@ -391,8 +393,11 @@ def _stepwise_epoch_check(gene, cfg, seed, epoch, state, Xtr, ytr, Xtr_d, ytr_d,
             d_stat = _bn_stat_deviation(tensors, net.get_params(), onet.get_flat(), conv_bias_gauge=(v == 0), steps=1, lr=cfg.lr)
             assert d_stat <= 1e-5, (where, d_stat)
             err = per_tensor_err(gene, v, cfg.classes, net.get_grads(), onet.grads_flat())
-            spikes = [k for k, x in err.items() if x > 1e-4]
-            assert len(spikes) <= max(2, len(err) // 4) and max(err.values()) <= 1e-1, (where, {k: err[k] for k in spikes})
+            worst = max(err.values())
+            assert worst <= 1e-1, (where, max(err, key=err.get), worst)
+            n_steps += 1
+            n_clean += worst <= 1e-4
+    assert 2 * n_clean >= n_steps, f"{tag} {gene} epoch {epoch}: only {n_clean} of {n_steps} steps free of tie flips"
 
 
 def resynchronised_fit_check(gene, cfg, Xtr, ytr, Xva, yva, seed, expected=None, loss_tol=1e-4, pred_tol=1, stat_tol=5e-5, tag=""):
