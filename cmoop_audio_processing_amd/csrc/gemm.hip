@@ -1515,6 +1515,11 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     if (mode == GEMM_BF16X3 && bco < 128) mode = GEMM_FP32;
     dim3 grid(cdiv(g.K, bki), cdiv(N, bco), S);
     int gkt = 0, gct = 0;
+    // (Measured, not adopted, round 3: row slices on the FASTEST grid axis, so that with round-robin dispatch every K tile of a
+    // slice runs on XCD s % 8 and co-resident K tiles share the slice's dY / input rows in one L2 -- PMC shows 36 % L2 hit
+    // rate and 1.1 GB of fabric reads per launch on 64->64 k5 @101x40 with K tiles fastest.  95.2 vs 107.2 TFLOP/s there,
+    // 89.1 vs 99.2 @51x20, no change on 128->128: like the XCD-grouped grid, concentrating a slice's lines on one L2 is slower
+    // than spreading them over eight L2s and the Infinity Cache.)
     if (wgrad_xcd_grouped() && mode == GEMM_FP32 && S >= 8) {
         gkt = (int)grid.x; gct = (int)grid.y;
         grid = dim3((unsigned)(cdiv(S, 8) * 8 * gkt * gct), 1, 1);

@@ -7,7 +7,8 @@ i=0
 for envs in "$@"; do
   i=$((i+1))
   [ "$envs" = "-" ] && envs=""
-  line=$(env $envs timeout -k 10 400 python bench.py --epochs 2 --steps 1 --warmup 1 --no-cpu-baseline 2> "$OUT/run$i.err")
+  BENCH_ARGS=$(echo "$envs" | tr " " "\n" | grep "^ARGS=" | sed "s/^ARGS=//" | tr "," " "); envs=$(echo "$envs" | tr " " "\n" | grep -v "^ARGS=" | tr "\n" " ")
+  line=$(env $envs timeout -k 10 400 python bench.py --epochs 2 --steps 1 --warmup 1 --no-cpu-baseline $BENCH_ARGS 2> "$OUT/run$i.err")
   rc=$?
   echo "$line" > "$OUT/run$i.json"
   python - "$envs" "$OUT/run$i.json" "$rc" <<'PY' | tee -a "$OUT/summary.txt"
