@@ -61,6 +61,10 @@ def main():
         res = ev.compute_objectives_and_constraints(population)
         calls.append({"candidates": len(population), "seconds": round(time.perf_counter() - t0, 3),
                       "wall_clock_s": round(time.perf_counter() - t_start, 3), "epochs_run": list(ev.last_epochs_run)})
+        if rank == 0 and a.trace:      # partial trace after every call: a run cut off by a time limit still leaves its stamps
+            with open(a.trace + ".partial", "w") as fh:
+                json.dump({"pop": a.pop, "gen": a.gen, "clips": a.clips, "hard_synthetic": a.hard, "n_train": n_tr, "evaluate_calls": calls,
+                           "objectives_of_last_call": [r["objs"] for r in res]}, fh)
         if rank == 0:
             print(f"[search] evaluate call {len(calls)}: {len(population)} candidates in {calls[-1]['seconds']} s, "
                   f"epochs run min/mean/max {min(ev.last_epochs_run)}/{sum(ev.last_epochs_run) / len(population):.1f}/"

@@ -2,13 +2,14 @@
 # CMOOP_DEBUG_SKIP_ELEM drops whole kernel families (results are garbage, only the wall time means something):
 #   1 BatchNorm (statistics finalize, apply, fused pool forms, backward reduce / apply)   2 first conv (C_in = 1) fwd / wgrad
 #   4 dense head + GAP + softmax-CE                                                        8 max-pool, add+ReLU
-#  16 Adam (with the slab sums), step state, shuffle, init                                32 split-K combine + flip-transpose
+#  16 Adam (with the slab sums), step state                                               32 split-K combine + flip-transpose
 # Apply, make, run tools/debug/skip_run.sh on the GPU, then `git checkout` the three files and rebuild.
 import re
 root = '/root/repo/cmoop_audio_processing_amd/csrc/'
 FAMILY = [(1, r'colreduce_kernel|bn_\w+|scale_shift_kernel'), (2, r'conv1_\w+'),
           (4, r'dense_\w+|gap_\w+|softmax_ce_kernel|colsum_\w+|confusion_kernel'), (8, r'maxpool_\w+|add_relu_kernel'),
-          (16, r'adam_\w+|step_advance_kernel|epoch_permutation_kernel|fill_kernel|glorot_init_kernel'),
+          (16, r'adam_\w+|step_advance_kernel'),   # NOT the shuffle / init kernels: skipping epoch_permutation_kernel left the first conv's
+          # gather indices undefined and faulted the GPU in round 2 (profiles/r02_non_gemm_cost_upper_bound.txt); the gather is clamped since round 3
           (32, r'splitk_combine_kernel|flip_transpose_all_kernel')]
 hdr = '''
 #include <cstdlib>
