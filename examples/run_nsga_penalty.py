@@ -55,6 +55,14 @@ def main():
                                                compute=a.compute, fpr_variant=a.fpr))
     calls = []
     t_start = time.perf_counter()
+    if rank == 0:      # a generation at full size takes minutes: keep stderr alive (job runners kill silent commands)
+        import threading
+        stop = threading.Event()
+
+        def heartbeat():
+            while not stop.wait(60.0):
+                print(f"[search] running, {time.perf_counter() - t_start:.0f} s, {len(calls)} evaluate calls done", file=sys.stderr, flush=True)
+        threading.Thread(target=heartbeat, daemon=True).start()
 
     def evaluate(population):
         t0 = time.perf_counter()
