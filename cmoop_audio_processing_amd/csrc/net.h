@@ -155,6 +155,7 @@ class Net : public GemmHook {
     int feature_T() const { return T_; }
     int feature_F() const { return F_; }
     long long steps_done() const { return step_; }
+    long long iterations_done() const { return iterations_; }
 
   private:
     void build_plan();

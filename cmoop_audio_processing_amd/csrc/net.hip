@@ -1013,7 +1013,8 @@ EvalResult fit_and_read_out(Net& net, const NetConfig& cfg, const Dataset& ds, u
         int wait = 0, best_epoch = -1;
         bool have_best = false, preds_are_final = false;
         net.set_gather_rows(ds.n_train);
-        net.begin_fit((int64_t)cfg.epochs * ((ds.n_train + cfg.batch - 1) / cfg.batch));
+        // (a session net that has already trained continues from its own optimizer.iterations)
+        net.begin_fit(net.iterations_done() + (int64_t)cfg.epochs * ((ds.n_train + cfg.batch - 1) / cfg.batch));
         for (int epoch = 0; epoch < cfg.epochs; ++epoch) {
             if (cfg.shuffle && ds.n_train <= EPOCH_PERMUTATION_DEVICE_MAX) {
                 launch_epoch_permutation(seed, (uint32_t)epoch, ds.n_train, d_idx, stream);   // no host sort, no H2D
