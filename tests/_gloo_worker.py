@@ -100,8 +100,16 @@ def main():
         for i in iter(pull, -1):
             mine[i] = [float(i), float(rank)]
         return mine
-    out_h = queued_map(local_heads, costs_h, 2, "test/queue/heads", device="cpu", slots=2)
+    stats = {}
+    out_h = queued_map(local_heads, costs_h, 2, "test/queue/heads", device="cpu", slots=2, stats=stats)
     assert first == heads_h[rank], (first, heads_h[rank])
+    # r3: the diagnostics that make a multi-GPU line explain itself -- this rank's share of the deal, its fetch-adds on the
+    # shared counter (7 queued candidates + one exhausted pull per rank in total) with their round trips, the all-gather
+    assert stats["dealt_here"] == 2 and stats["store_adds"] >= 1 and stats["store_add_us_mean"] > 0 and stats["local_s"] > 0
+    assert stats["all_gather_ms"] > 0 and stats["store_add_us_max"] >= stats["store_add_us_mean"]
+    tot = torch.tensor([float(stats["store_adds"])], dtype=torch.float64)
+    dist.all_reduce(tot)
+    assert int(tot.item()) == 7 + world, tot
     assert out_h[:, 0].tolist() == [float(i) for i in range(11)]
     assert [int(out_h[i, 1]) for i in (0, 6)] == [0, 0] and [int(out_h[i, 1]) for i in (2, 4)] == [1, 1]
     # empty generation and fewer candidates than ranks through the queue

@@ -195,7 +195,8 @@ def test_one_step_gradients_of_the_heavy_bench_genes_at_101x40_batch_64(gene):
     kernel-level cases above."""
     classes, seed, T, F = 10, 21, 101, 40
     floor, l_gate = (3e-2, 1e-2) if gene[2] else (5e-3, 2e-3)
-    cfg = EvalConfig(variant="A", classes=classes, batch=64, eval_batch=64, profile_every=1)
+    cfg = EvalConfig(variant=variant, classes=classes, batch=64, eval_batch=64, profile_every=1)
+    vi = G.VARIANT_NAMES[variant]
     X, y = _learnable_batch(64, T, F, classes, 11)
     Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
     o32, o64 = ON.OracleNet(gene, _ocfg(cfg), seed), ON.OracleNet(gene, _ocfg(cfg), seed, dtype=torch.float64)
@@ -207,11 +208,11 @@ def test_one_step_gradients_of_the_heavy_bench_genes_at_101x40_batch_64(gene):
             o32.train_step(X[:b], y[:b])
             o64.train_step(X[:b], y[:b])
             g_hip, g_32, g_64 = net.get_grads(), o32.grads_flat(), o64.grads_flat()
-            e_hip = _per_tensor_err(gene, 0, classes, g_hip, g_64)
-            e_o32 = _per_tensor_err(gene, 0, classes, g_32, g_64)
-            l_hip, l_o32 = _rel_l2_per_tensor(gene, 0, classes, g_hip, g_64), _rel_l2_per_tensor(gene, 0, classes, g_32, g_64)
+            e_hip = _per_tensor_err(gene, vi, classes, g_hip, g_64)
+            e_o32 = _per_tensor_err(gene, vi, classes, g_32, g_64)
+            l_hip, l_o32 = _rel_l2_per_tensor(gene, vi, classes, g_hip, g_64), _rel_l2_per_tensor(gene, vi, classes, g_32, g_64)
             worst, wl = max(e_hip, key=e_hip.get), max(l_hip, key=l_hip.get)
-            print(f"{gene} B={b}: worst max-abs HIP-vs-fp64 {worst} {e_hip[worst]:.2e} (fp32 oracle there {e_o32[worst]:.2e}, its own worst "
+            print(f"{variant}{gene} B={b}: worst max-abs HIP-vs-fp64 {worst} {e_hip[worst]:.2e} (fp32 oracle there {e_o32[worst]:.2e}, its own worst "
                   f"{max(e_o32.values()):.2e}); worst rel-L2 {wl} {l_hip[wl]:.2e} (oracle's worst {max(l_o32.values()):.2e}); "
                   f"median max-abs HIP {np.median(list(e_hip.values())):.1e} / oracle {np.median(list(e_o32.values())):.1e}")
             for name in e_hip:
