@@ -735,6 +735,7 @@ def main(argv=None, t_origin=None):
             rc = 2
     stop_hb.set()
     if world > 1:
+        dist.barrier()          # rank 0 ran the roofline legs and printed: every rank leaves the group together
         dist.destroy_process_group()
     return rc
 
