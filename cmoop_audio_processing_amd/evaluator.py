@@ -148,6 +148,13 @@ def _dist():
     return None
 
 
+def _multi(dist) -> bool:
+    """More than one rank -- or CMOOP_FORCE_COLLECTIVES=1, which sends a ONE-rank process group through the same store
+    counter and all_gather as N ranks (how the RCCL path is executed on a single-GPU box: tests/test_gpu_net.py)."""
+    import os
+    return dist is not None and (dist.get_world_size() > 1 or os.environ.get("CMOOP_FORCE_COLLECTIVES") == "1")
+
+
 def sharded_map(local_fn: Callable[[List[int]], np.ndarray], costs: Sequence[float], width: int,
                 device: str = "cpu") -> np.ndarray:
     """Evaluate items 0..n-1 across the ranks of the default process group.
@@ -158,7 +165,7 @@ def sharded_map(local_fn: Callable[[List[int]], np.ndarray], costs: Sequence[flo
     """
     n = len(costs)
     dist = _dist()
-    if dist is None or dist.get_world_size() == 1:
+    if not _multi(dist):
         return np.asarray(local_fn(list(range(n))), dtype=np.float64).reshape(n, width)
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -237,7 +244,7 @@ def queued_map(local_pull_fn: Callable[..., Dict[int, Sequence[float]]], costs: 
     add_us: List[float] = []
     n = len(costs)
     dist = _dist()
-    multi = dist is not None and dist.get_world_size() > 1
+    multi = _multi(dist)
     world = dist.get_world_size() if multi else 1
     order, workers, heads = queue_plan(costs, world, slots if slots is not None else max(n, 1))
     if slots is None:
@@ -411,7 +418,7 @@ class PopulationEvaluator:
         v = G.VARIANT_NAMES[self.config.variant]
         costs = [float(G.fwd_flops_per_sample(g, v, self.config.classes, self.T, self.F)) for g in gl]
         dist = _dist()
-        multi = dist is not None and dist.get_world_size() > 1
+        multi = _multi(dist)
         self._generation += 1
         if not n:
             res = np.zeros((0, 6))

@@ -953,3 +953,52 @@ def test_net_parity_under_forced_bf16x3():
                         "test_init_step_grads_and_eval_parity or test_partial_batch or test_classes_35 or "
                         "test_evaluate_individual_protocol_parity"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(ENV_MODE != "", reason="already inside a mode-forced child run")
+def test_rccl_executes_the_generation_exchange_on_a_one_rank_group():
+    """'one RCCL all_gather of objective vectors per generation'.  No multi-GPU node has been in reach, so until
+    round 3 RCCL had never executed a single call of this repo.  torch.distributed backend 'nccl' IS RCCL on ROCm and accepts
+    a ONE-rank group on one GPU: with CMOOP_FORCE_COLLECTIVES=1 the evaluator takes its N-rank path there -- the candidates
+    go through the shared c10d-store counter (dynamic schedule) or the LPT buckets (static), and the [n, width] float64
+    objective matrix through `all_gather_into_tensor` on device tensors -- and must return what the plain path returns, bit
+    for bit.  (Degenerate in the number of peers, real in every call: process-group creation with a device id, the store
+    fetch-add, the collective on HBM-resident float64 tensors, the ownership check.)"""
+    code = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CMOOP_ROOT"]); sys.path.insert(0, os.path.join(os.environ["CMOOP_ROOT"], "tests"))
+from cmoop_audio_processing_amd import EvalConfig, PopulationEvaluator, genes as G
+from test_gpu_net import make_split
+import random
+torch.cuda.set_device(0)
+Xtr, ytr, Xva, yva = make_split(96, 64, 21, 12, 10, 31)
+rng = random.Random(0)
+pop = [G.random_hparams(rng) for _ in range(5)]
+base = dict(epochs=2, batch=32, eval_batch=64, seed=5, n_slots=3, early_stop=False)
+plain = PopulationEvaluator(Xtr, ytr, Xva, yva, EvalConfig.preset("nsga_penalty", **base)).compute_objectives_and_constraints(pop)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % int(os.environ["CMOOP_PORT"]), rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+os.environ["CMOOP_FORCE_COLLECTIVES"] = "1"
+out = {}
+for schedule in ("dynamic", "static"):
+    ev = PopulationEvaluator(Xtr, ytr, Xva, yva, EvalConfig.preset("nsga_penalty", schedule=schedule, **base))
+    res = ev.compute_objectives_and_constraints(pop)
+    assert [r["objs"] for r in res] == [r["objs"] for r in plain] and [r["CV"] for r in res] == [r["CV"] for r in plain], schedule
+    assert ev.last_rank_of == [0] * 5
+    out[schedule] = dict(ev.last_queue_stats)
+    assert ev.compute_objectives_and_constraints([]) == []
+assert out["dynamic"]["all_gather_ms"] > 0 and out["dynamic"]["store_adds"] >= 1, out
+t = torch.ones(4, dtype=torch.float64, device="cuda"); dist.all_reduce(t); assert float(t.sum()) == 4.0
+print("RCCL_ONE_RANK_OK backend=%s" % dist.get_backend(), json.dumps(out["dynamic"]))
+dist.destroy_process_group()
+'''
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CMOOP_ROOT=root, CMOOP_PORT=str(port), MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK backend=nccl" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
