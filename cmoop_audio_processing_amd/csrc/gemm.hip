@@ -168,9 +168,10 @@ std::string gemm_kernel_name(int cls, int code) {
         return "igemm_fwd_kernel<" + std::to_string(bm) + ", " + std::to_string(bn) + ", " + std::to_string(bk) + ", " +
                std::to_string(wm) + ", " + std::to_string(mode) + ">";
     }
-    const int mode = code / 1000000, c = code % 1000000;
+    // launch_igemm_wgrad's code: mode * 10^7 + (64-row chunks ? 10^6 : 0) + BCO * 1000 + BKI
+    const int mode = code / 10000000, mc = (code / 1000000) % 10 ? 64 : 32, c = code % 1000000;
     const std::string tile = std::to_string(c / 1000) + ", " + std::to_string(c % 1000);
-    return mode == GEMM_FP32 ? "igemm_wgrad_kernel<" + tile + ">"
+    return mode == GEMM_FP32 ? "igemm_wgrad_kernel<" + tile + ", " + std::to_string(mc) + ">"
                              : "igemm_wgrad_bf16_kernel<" + tile + ", " + (mode == GEMM_BF16X3 ? "3" : "1") + ">";
 }
 
@@ -1057,13 +1058,13 @@ void launch_build_rowtab(const ConvGeom& cg, void* tab, hipStream_t s) {
     CMOOP_HIP(hipGetLastError());
 }
 
-template <int BCO, int BKI>
+template <int BCO, int BKI, int MC = 32>   // MC: pixel rows per chunk; MC = 64 runs a SINGLE LDS image (two barriers per chunk)
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                           float* __restrict__ P, GeomDev g, int rows_per_slice,
                                                           float* __restrict__ Pbias, size_t slab_stride,
                                                           const uint2* __restrict__ rowtab, int tab_rows, int grouped_kt,
                                                           int grouped_ct, int grouped_slices) {
-    constexpr int MC = 32;
+    constexpr int NBUF = MC == 32 ? 2 : 1;
     constexpr int LDX = BKI + 16;                          // == 16 mod 32
     constexpr int LDY = (BCO == 16) ? 16 : BCO + 16;
     constexpr int CT = BCO / 16, KT = BKI / 16;             // co tiles, k tiles of the block
@@ -1073,8 +1074,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     constexpr int TPRX = BKI / 4, RPPX = 256 / TPRX, XPASS = MC / RPPX;
     constexpr int TPRY = BCO / 4, RPPY = 256 / TPRY;
     constexpr int YPASS = (MC + RPPY - 1) / RPPY;
-    __shared__ __attribute__((aligned(16))) float Xs[2][MC * LDX];
-    __shared__ __attribute__((aligned(16))) float Ys[2][MC * LDY];
+    __shared__ __attribute__((aligned(16))) float Xs[NBUF][MC * LDX];
+    __shared__ __attribute__((aligned(16))) float Ys[NBUF][MC * LDY];
 
     const int t = threadIdx.x;
     // XCD-grouped 1-D grid (grouped_kt > 0): workgroups are dealt round-robin over the 8 XCDs, so linear id L runs on
@@ -1203,7 +1204,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
     }
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
+        const int buf = NBUF == 2 ? (c & 1) : 0;
         if (do_bias) {
 #pragma unroll
             for (int p = 0; p < YPASS; ++p) bsum += ry[p];   // ry still holds chunk c (rows past mend are zero)
@@ -1237,12 +1238,18 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
                     acc[c2][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1][c2], b[st & 1][kt], acc[c2][kt], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
-        if (c + 1 < nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
+        if constexpr (NBUF == 2) {
+            if (c + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+        } else {        // single image: every wave must have read chunk c's fragments before chunk c + 1 overwrites them
+            __syncthreads();
+            if (c + 1 < nchunks) store_chunk(0);
+            __syncthreads();
+        }
     }
 
     if (do_bias) {   // fixed-order reduction over the RPPY row lanes that share a column group
-        float* red = &Xs[0][0];                       // MC*LDX*2 >= 1024 floats, free after the loop's last barrier
+        float* red = &Xs[0][0];                       // >= 1024 floats, free after the loop's last barrier
         *reinterpret_cast<f32x4*>(&red[4 * t]) = bsum;
         __syncthreads();
         if (t < BCO && co0 + t < g.Cout) {
@@ -1483,6 +1490,16 @@ int wgrad_slices(const ConvGeom& g) {
     return S;
 }
 
+// 64-row chunks on a SINGLE LDS image for the <= 64-channel weight-gradient tiles (row-table gather only): the same LDS footprint
+// as two 32-row images, twice the MFMAs per chunk of fixed loop / wait / barrier overhead (the <64,128> tile runs 64 MFMAs per
+// wave and chunk against ~110 other instructions; PMC: 0.70 of the SIMD cycles in MFMA against 0.81 for <128,128>).  Round 3:
+// 64->64 k5 @101x40 107.2 -> 113.0 TFLOP/s, k3 95.8 -> 99.6, 32->32 k5 89.6 -> 92.1, 16->16 k3 43.3 -> 47.7; the job 2 179 -> 2 181 / 2 187
+// evals/h (two A/B pairs).  CMOOP_WGRAD_MC64=0 restores 32-row chunks everywhere.
+static bool wgrad_mc64(bool rowtab_gather, int mode, int bco) {
+    static const bool on = [] { const char* v = std::getenv("CMOOP_WGRAD_MC64"); return !(v && v[0] == '0'); }();
+    return on && rowtab_gather && mode == GEMM_FP32 && bco <= 64;
+}
+
 // instantiation code + flags of the weight-gradient launch for this geometry with S row slices (host arithmetic only)
 int igemm_wgrad_plan(const ConvGeom& g, int S, int mode_req, bool have_rowtab, int* flags_out) {
     igemm_check_range(g);
@@ -1492,7 +1509,7 @@ int igemm_wgrad_plan(const ConvGeom& g, int S, int mode_req, bool have_rowtab, i
     if (mode == GEMM_BF16X3 && bco < 128) mode = GEMM_FP32;
     const bool rt = have_rowtab && g.KH * g.KW <= 32;
     if (flags_out) *flags_out = ((rt && mode == GEMM_FP32 && (N & 3) == 0) ? GEMM_FLAG_ROWTAB : 0) | (S > 1 ? GEMM_FLAG_SLABS : 0);
-    return mode * 1000000 + bco * 1000 + bki;
+    return mode * 10000000 + (wgrad_mc64(rt && (N & 3) == 0, mode, bco) ? 1000000 : 0) + bco * 1000 + bki;
 }
 
 int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom& cg, int S, hipStream_t s,
@@ -1503,7 +1520,6 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     if (g.M == 0) return 0;
     const size_t stride = slab_stride ? slab_stride : (size_t)g.Cout * g.K;
     int rps = cdiv(g.M, S);
-    rps = cdiv(rps, 32) * 32;
     const int N = g.Cout;
     const int bco = wgrad_bco(N);
     const int bki = wgrad_bki(g.M, g.Cout, g.K);
@@ -1547,10 +1563,13 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
             if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));                                       \
         }                                                                                                      \
     } while (0)
+    const bool use_mc64 = wgrad_mc64(rt != nullptr && (N & 3) == 0, mode, bco);     // (tab_rows covers whole 256-row tiles: rowtab_rows)
+    rps = use_mc64 ? cdiv(rps, 64) * 64 : cdiv(rps, 32) * 32;      // slices are whole chunks of the kernel's chunk depth
 #define CMOOP_WG2(BCO_, BKI_)                                                          \
     do {                                                                               \
         if (mode == GEMM_BF16X3) CMOOP_WGK((igemm_wgrad_bf16_kernel<BCO_, BKI_, 3>));  \
         else if (mode == GEMM_BF16) CMOOP_WGK((igemm_wgrad_bf16_kernel<BCO_, BKI_, 1>)); \
+        else if (use_mc64 && BCO_ <= 64) CMOOP_WGF((igemm_wgrad_kernel<(BCO_ <= 64 ? BCO_ : 64), BKI_, 64>)); \
         else CMOOP_WGF((igemm_wgrad_kernel<BCO_, BKI_>));                              \
     } while (0)
 #define CMOOP_WG(BCO_)                    \
@@ -1567,7 +1586,7 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
 #undef CMOOP_WGF
 #undef CMOOP_WGK
     CMOOP_HIP(hipGetLastError());
-    return mode * 1000000 + bco * 1000 + bki;
+    return mode * 10000000 + (use_mc64 ? 1000000 : 0) + bco * 1000 + bki;
 }
 
 // out[i] = sum_s P[s][i], fixed summation order.  Vector form: each thread owns one float4 column group,

@@ -75,7 +75,7 @@ std::string gemm_kernel_name(int cls, int code);
 
 // dWt[n][k] = sum_m dY[m][n] * im2col(X)[m][k], split over S row-slices into P[S][N][K].
 int wgrad_slices(const ConvGeom& g);
-// returns the instantiation code mode*1e6 + BCO*1000 + BKI of the kernel that was launched
+// returns the instantiation code mode*1e7 + (64-row chunks ? 1e6 : 0) + BCO*1000 + BKI of the kernel that was launched
 // Pbias (optional): [S][N] per-slice column sums of dY (the bias gradient), fused into the first K tile's blocks
 // slab_stride: floats between consecutive slices of P and of Pbias (0 = N*K, bias slabs packed [S][N]);
 // the trainer lays slices out as [S][N*K + N] so one reduction yields kernel and bias gradients.

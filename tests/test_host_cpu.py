@@ -298,7 +298,7 @@ def test_every_launch_variant_of_every_gene_has_a_gpu_parity_case():
         assert not missing, f"launch-path variants without a GPU parity case (topology {variant}): {missing}"
     assert len(covered) >= 30
     # the names are the ones rocprofv3 prints: the LDS-DMA instantiation carries MODE = 1
-    assert "igemm_fwd_kernel<128, 32, 32, 4, 1>+stats+tab" in covered and "igemm_wgrad_kernel<128, 128>+tab+slabs" in covered
+    assert "igemm_fwd_kernel<128, 32, 32, 4, 1>+stats+tab" in covered and "igemm_wgrad_kernel<128, 128, 32>+tab+slabs" in covered and "igemm_wgrad_kernel<64, 128, 64>+tab+slabs" in covered
 
 
 def test_32bit_byte_offset_guard_refuses_oversized_plans():
