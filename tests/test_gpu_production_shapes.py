@@ -156,10 +156,11 @@ def _learnable_batch(n, T, F, classes, seed):
 
 
 HEAVY_GENES = [
-    (64, 5, 1, 3, 4, 1),    # the heaviest gene of the bench's population class: 64 filters k5, BatchNorm, R = 3 (K = 512 head), dropout
-    (64, 3, 0, 3, 1, 0),    # 64 filters k3 without BatchNorm, R = 3
-    (32, 5, 0, 2, 3, 1),    # 32 filters k5 (the LDS-DMA tile), dropout
-    (64, 5, 1, 2, 2, 0),    # 64-filter BatchNorm gene, R = 2
+    ((64, 5, 1, 3, 4, 1), "A"),    # the heaviest gene of the bench's population class: 64 filters k5, BatchNorm, R = 3 (K = 512 head), dropout
+    ((64, 3, 0, 3, 1, 0), "A"),    # 64 filters k3 without BatchNorm, R = 3
+    ((32, 5, 0, 2, 3, 1), "A"),    # 32 filters k5 (the LDS-DMA tile), dropout
+    ((64, 5, 1, 2, 2, 0), "A"),    # 64-filter BatchNorm gene, R = 2
+    ((64, 5, 1, 3, 4, 1), "B"),    # topology B (sa_nsga_penalty.py:151-165): BatchNorm AFTER the ReLU, pool after the first conv
 ]
 
 
@@ -178,8 +179,8 @@ def _rel_l2_per_tensor(gene, variant, classes, a, b):
     return out
 
 
-@pytest.mark.parametrize("gene", HEAVY_GENES)
-def test_one_step_gradients_of_the_heavy_bench_genes_at_101x40_batch_64(gene):
+@pytest.mark.parametrize("gene,variant", HEAVY_GENES)
+def test_one_step_gradients_of_the_heavy_bench_genes_at_101x40_batch_64(gene, variant):
     """One optimiser step of a whole heavy candidate at the bench's shapes (101x40, batch 64, then a partial batch of 37):
     per-tensor gradients HIP vs the FLOAT64 oracle; then inference from the updated weights.  Every MFMA launch of the two
     steps is sampled (profile_every = 1) and enters the coverage set.
