@@ -191,11 +191,11 @@ def test_one_step_gradients_of_the_heavy_bench_genes_at_101x40_batch_64(gene, va
     of it; BatchNorm's backward couples all positions).  The fp32 oracle itself lands 1e-7 ... 8e-3 (max) away from the
     float64 one per tensor, and its two CPU conv algorithms disagree on WHICH tensors are hit (res1_conv1/kernel: 1.2e-4
     vs 5.0e-3).  Either fp32 side draws these flips independently, so the gate is: max-abs error per tensor <= 5x the fp32
-    oracle's own or a floor (5e-3 without BatchNorm, 3e-2 with), AND relative L2 error per tensor <= 2e-3 / 1e-2 -- a
+    oracle's own or a floor (5e-3 without BatchNorm, 5e-2 with: single flips of 3.5e-2 were observed), AND relative L2 error per tensor <= 2e-3 / 1e-2 -- a
     corrupt slab, a missed K chunk or a wrong tile are broad O(1e-1..1) errors; kernel arithmetic is gated at 2e-5 by the
     kernel-level cases above."""
     classes, seed, T, F = 10, 21, 101, 40
-    floor, l_gate = (3e-2, 1e-2) if gene[2] else (5e-3, 2e-3)
+    floor, l_gate = (5e-2, 1e-2) if gene[2] else (5e-3, 2e-3)
     cfg = EvalConfig(variant=variant, classes=classes, batch=64, eval_batch=64, profile_every=1)
     vi = G.VARIANT_NAMES[variant]
     X, y = _learnable_batch(64, T, F, classes, 11)
