@@ -1497,6 +1497,8 @@ int wgrad_slices(const ConvGeom& g) {
 // evals/h (two A/B pairs).  CMOOP_WGRAD_MC64=0 restores 32-row chunks everywhere.
 static bool wgrad_mc64(bool rowtab_gather, int mode, int bco) {
     static const bool on = [] { const char* v = std::getenv("CMOOP_WGRAD_MC64"); return !(v && v[0] == '0'); }();
+    // (the 128-channel tile does NOT gain: <128,128> 130.6 -> 126.8 TFLOP/s on 128->128 k5, 120.6 -> 112.4 on 512->512 k3 -- it already runs
+    // 128 MFMAs per chunk and the second barrier costs more than the amortisation buys)
     return on && rowtab_gather && mode == GEMM_FP32 && bco <= 64;
 }
 
