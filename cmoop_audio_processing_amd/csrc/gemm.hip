@@ -953,6 +953,8 @@ static FwdChoice choose_fwd(const ConvGeom& cg, const GemmEpilogue& ep, size_t w
     static const int dma_env = [] { const char* v = std::getenv("CMOOP_DMA"); return v ? std::atoi(v) : 1; }();
     c.use_dma = dma_env && c.mode == GEMM_FP32 && (cg.Cin % 32 == 0) && cg.KH * cg.KW <= 32 && c.bk32_tile && c.bm == 128 && c.bn == 32;
     if (c.use_dma) c.mode = GEMM_FP32_DMA;      // the instantiation's MODE parameter (rocprofv3 prints it)
+    // (Measured, not adopted, round 3: the many-wave 128x64 grids on 32-deep chunks with a SINGLE LDS image -- the trick that
+    // helped the <= 64-channel weight gradient: forward 114.5 vs 123.0 TFLOP/s on 64->64 k5 @101x40, dgrad 105.7 vs 114.1 on k3.)
     const int bk = c.bk32_tile ? 32 : 16;
     c.flags = (c.splits > 1 ? GEMM_FLAG_SPLITK : 0) | (c.stats ? GEMM_FLAG_STATS : 0) | (c.balanced_wgs ? GEMM_FLAG_BALANCED : 0) |
               ((have_rowtab && (cg.Cin % bk) == 0 && cg.KH * cg.KW <= 32) ? GEMM_FLAG_ROWTAB : 0);
