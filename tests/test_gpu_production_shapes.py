@@ -26,8 +26,10 @@ from oracle.net import conv_same
 pytestmark = pytest.mark.gpu
 
 ENV_MODE = os.environ.get("CMOOP_GEMM_MODE", "")
-if ENV_MODE:
-    pytest.skip("production-shape parity is defined for the exact-fp32 product path", allow_module_level=True)
+if ENV_MODE not in ("", "bf16x3"):
+    pytest.skip("production-shape parity is defined for the exact-fp32 product path (and re-run under the fp32-accurate bf16x3 mode)",
+                allow_module_level=True)
+fp32_only = pytest.mark.skipif(ENV_MODE != "", reason="exact-fp32 product path only")
 
 #: launch-path variants (cmoop_last_kernels / cmoop_profile_variant strings) exercised by a parity comparison in this
 #: module, filled as the tests run; the coverage test at the bottom reads it
@@ -103,9 +105,24 @@ def test_production_conv_shapes_through_the_trainer_launch_path(B, H, W, Cin, Co
           f"dx {e_dx:.1e} dw {e_dw:.1e} db {e_db:.1e}  {sorted(set(names))}")
     assert e_y < 2e-5 and e_y2 < 2e-5 and e_dx < 2e-5 and e_dw < 5e-5 and e_db < 5e-5
     assert fused.value in (0, 1) and e_s < 2e-6 and e_q < 2e-6
-    COVERED.update(names)
+    if not ENV_MODE:
+        COVERED.update(names)
 
 
+@fp32_only
+def test_production_conv_shapes_under_the_fp32_accurate_bf16x3_mode():
+    """The opt-in bf16x3 matrix-core mode (every fp32 operand split exactly into three bf16 values, six bf16 MFMA terms:
+    fp32-accurate, not bit-exact) through the same 31 production shapes and the same trainer launch path, at the exact
+    path's tolerances -- in a child process, because CMOOP_GEMM_MODE is read once per process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CMOOP_GEMM_MODE="bf16x3")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "production_conv_shapes_through"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "31 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@fp32_only
 @pytest.mark.parametrize("M,N,K,relu", [(64, 512, 512, 1), (64, 256, 512, 1), (37, 64, 128, 1), (64, 10, 64, 0), (64, 35, 64, 0), (256, 512, 512, 1)])
 def test_dense_head_kernels(M, N, K, relu):
     """dense.hip (MLP head, nsga_penalty.py:306-330): forward, dgrad with the ReLU mask, wgrad, bias gradient; K = 512 walks
@@ -179,6 +196,7 @@ def _rel_l2_per_tensor(gene, variant, classes, a, b):
     return out
 
 
+@fp32_only
 @pytest.mark.parametrize("gene,variant", HEAVY_GENES)
 def test_one_step_gradients_of_the_heavy_bench_genes_at_101x40_batch_64(gene, variant):
     """One optimiser step of a whole heavy candidate at the bench's shapes (101x40, batch 64, then a partial batch of 37):
@@ -230,6 +248,7 @@ def test_one_step_gradients_of_the_heavy_bench_genes_at_101x40_batch_64(gene, va
     COVERED.update(_lib.profile_variants())
 
 
+@fp32_only
 def test_fused_bn_pool_kernels_equal_the_unfused_pair_bit_for_bit(monkeypatch):
     """bn_pool_fwd / bn_pool_bwd_* (BatchNorm-apply (+ReLU) + MaxPool SAME in one pass, the pool's backward folded into the
     BatchNorm backward) claim bit-identical results to scale_shift + maxpool_fwd / maxpool_bwd + bn_bwd_*.
@@ -259,6 +278,7 @@ def test_fused_bn_pool_kernels_equal_the_unfused_pair_bit_for_bit(monkeypatch):
         assert a[2] == b[2] and np.array_equal(a[3], b[3])
 
 
+@fp32_only
 def test_a_corrupt_shuffle_index_cannot_address_outside_the_resident_tensor():
     """the first-layer kernels and the loss gather rows through idx without a bound; the only producer is the
     device permutation, but a poisoned buffer would fault the GPU.  With the row count set (the trainer always sets it),
@@ -279,6 +299,7 @@ def test_a_corrupt_shuffle_index_cannot_address_outside_the_resident_tensor():
         assert np.array_equal(g_bad.view(np.uint32), np.array(net.get_grads()).view(np.uint32))
 
 
+@fp32_only
 def test_every_launch_variant_of_the_pop40_job_is_covered_by_a_parity_case():
     """Coverage assertion: run the bench's population (40 genes of random.Random(0), topology A,
     101x40, batch 64, eval_batch 256) with EVERY MFMA launch sampled, collect the launch-path variants it used --
