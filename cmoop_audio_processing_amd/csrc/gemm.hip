@@ -164,6 +164,8 @@ std::string gemm_kernel_name(int cls, int code) {
     if (cls == 0) {
         const int mode = code / 100000000, c = code % 100000000;
         const int bm = c / 100000, bn = (c / 100) % 1000, bk = c % 100;
+        if (mode == GEMM_FP32_HALO)
+            return "halo_fwd_kernel<" + std::to_string(bk) + ", " + std::to_string(bm) + ", " + std::to_string(bn) + ", " + (bn >= 64 ? "2>" : "4>");
         const int wm = (bm == bn) ? 2 : 4;   // wave layout of each instantiation (launch_igemm_fwd)
         return "igemm_fwd_kernel<" + std::to_string(bm) + ", " + std::to_string(bn) + ", " + std::to_string(bk) + ", " +
                std::to_string(wm) + ", " + std::to_string(mode) + ">";
@@ -722,6 +724,233 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     }   // piece loop
 }
 
+// ---------------------------------------------------------------------------
+// Halo-tiled direct convolution on the fp32 MFMA (stride 1, SAME padding, odd square window): forward-type launches
+// (forward, and dgrad with the flip-transposed kernel) of the layers with enough output pixels to fill the chip un-split.
+//
+// The implicit GEMM above re-gathers a tile's A operand once per filter tap (25x for k5) and pays for it in issue
+// slots: per 16-k chunk and wave 2-4 global loads, as many LDS stores, a barrier and the address VALU, against 32-64
+// MFMAs.  Here a workgroup stages the INPUT HALO of its 128 consecutive output pixels once per 16-channel chunk
+// (~20 KiB instead of 25 x 8 KiB) and then runs all KS*KS taps on it: an A fragment of tap (ky, kx) is the fragment of
+// tap (0, 0) at a CONSTANT LDS byte offset (ky * WP + kx) * 96, which goes into the ds_read's immediate field.  The B
+// fragments (16 output channels x 16 k per wave instruction) are read straight from global memory in the MFMA lane
+// layout, one tap ahead (the weights of a layer are L1 / L2 resident), so the steady state per tap and wave is
+// RT ds_read_b128 + CT buffer_load_b128 + 4 RT CT MFMAs with NO barrier, NO LDS store and NO vector address arithmetic;
+// the two barriers of the halo refill come once per KS*KS taps.
+//
+// Tiles are the same flat 128-row M tiles as the implicit GEMM (so the epilogue, the BatchNorm statistics partials and
+// the tile order are shared).  A tile may cross image boundaries: rows live in a VIRTUAL tall image, image b at virtual
+// rows [b (H + R), b (H + R) + H) with R = KS / 2 zero rows between neighbours -- one gap serves as bottom padding of
+// the image above and top padding of the image below, and the tap shift stays a constant offset across the boundary.
+// Halo pixels are stored [virtual row][column][16 channels + 8 pad]; the row pitch WP is W + KS - 1 rounded up to a
+// multiple of 8 pixels, so the pixel index of consecutive output pixels stays consecutive mod 8 across a row wrap and
+// the ds_read_b128 fragments are conflict-free like the implicit GEMM's (pitch 24 floats).
+// ---------------------------------------------------------------------------
+struct HaloDev {
+    int WP, rows_max, VH;                  // halo row pitch (pixels), rows the LDS image holds, H + R
+    uint32_t wp_magic, wp_shift, vh_magic, vh_shift;
+};
+__host__ __device__ constexpr int halo_nst(int bm) { return bm == 256 ? 11 : 9; }
+
+template <int KS, int BM, int BN, int WM>   // BM x BN output tile (128 x 64; 256 x 32 / 256 x 16 for the narrow layers), WM x (4 / WM) waves
+__global__ __launch_bounds__(256, 2) void halo_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                          float* __restrict__ Y, GeomDev g, EpiDev e, HaloDev h) {
+    constexpr int WN = 4 / WM, RT = BM / WM / 16, CT = BN / WN / 16, R = KS / 2, T = KS * KS;
+    constexpr int PITCH = 24;      // floats per halo pixel: 16 channels + 8 pad
+    constexpr int NST = halo_nst(BM);   // staged float4 per thread and channel chunk (host checks rows_max * WP * 4 <= NST * 256)
+    static_assert(RT >= 1 && CT >= 1, "tile too small for the wave layout");
+    extern __shared__ __attribute__((aligned(16))) float halo[];
+
+    const int t = threadIdx.x;
+    int mtile = blockIdx.x;
+    {   // XCD-aware tile order, as in igemm_fwd_kernel: neighbouring tiles share halo rows in one XCD's L2
+        const int nwg = gridDim.x, xcd = mtile & 7, idx = mtile >> 3;
+        const int qn = nwg >> 3, rn = nwg & 7;
+        mtile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+    }
+    const int ntile = blockIdx.y;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
+    const int wrow = (wave / WN) * (BM / WM), wcol = (wave % WN) * (BN / WN);
+
+    // output pixel m -> virtual row (b (H + R) + y) and column
+    auto vrow = [&](int m, int& x) {
+        const int b = fastdiv(m, g.ohw_magic, g.ohw_shift), r = m - b * g.OHW;
+        const int y = fastdiv(r, g.ow_magic, g.ow_shift);
+        x = r - y * g.OW;
+        return b * h.VH + y;
+    };
+    int xdummy;
+    const int vbase = vrow(m0, xdummy);                              // virtual row of the tile's first pixel
+    const int vlast = vrow(min(m0 + BM, g.M) - 1, xdummy);
+    const int items = (vlast - vbase + 1 + 2 * R) * h.WP * 4;        // float4 slots of this tile's halo (pad columns included)
+
+    // staging descriptors: slot i = t + 256 it -> halo pixel i >> 2 (row-major over [rows][WP]), channels 4 (i & 3) ...
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X), 0, (int)((uint32_t)g.B * g.H * g.W << g.cshift) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, g.Cout * g.K * 4, 0x00020000);
+    uint32_t s_voff[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int i = t + 256 * it, pix = i >> 2, j = i & 3;
+        const int hy = fastdiv(pix, h.wp_magic, h.wp_shift), hx = pix - hy * h.WP;
+        const int v = vbase - R + hy, vc = max(v, 0);
+        const int b = fastdiv(vc, h.vh_magic, h.vh_shift), y = vc - b * h.VH;
+        const bool ok = i < items && v >= 0 && b < g.B && y < g.H && hx >= R && hx < g.W + R;
+        s_voff[it] = ok ? (uint32_t)(((((b * g.H + y) * g.W + hx - R) << g.cshift) + 4 * j) * 4) : 0xFFFFFFFFu;
+    }
+    float* const st_dst = halo + (t >> 2) * PITCH + (t & 3) * 4;     // + it * 64 * PITCH floats
+    f32x4 st[NST];
+    auto stage_load = [&](int cc) {
+#pragma unroll
+        for (int it = 0; it < NST; ++it)
+            st[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)s_voff[it], cc * 64, 0));
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int it = 0; it < NST; ++it)
+            if (t + 256 * it < items) *reinterpret_cast<f32x4*>(st_dst + it * 64 * PITCH) = st[it];
+    };
+
+    // fragment addresses: lane (lr, q) reads channels 4q..4q+3 of output pixel (wrow + 16 rt + lr) shifted by the tap
+    const float* a_ptr[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        int x;
+        const int v = vrow(min(m0 + wrow + rt * 16 + lr, g.M - 1), x);
+        a_ptr[rt] = halo + ((v - vbase) * h.WP + x) * PITCH + 4 * q;
+    }
+    uint32_t b_voff[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = n0 + wcol + ct * 16 + lr;
+        b_voff[ct] = col < g.Cout ? (uint32_t)(col * g.K + 4 * q) * 4u : 0xFFFFFFFFu;
+    }
+    const int wp_f = h.WP * PITCH;             // floats per halo row
+    auto load_b = [&](int cc, int tap, f32x4 (&b)[CT]) {
+        const int soff = ((tap << g.cshift) + cc * 16) * 4;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            b[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)b_voff[ct], soff, 0));
+    };
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ncc = g.Cin >> 4;
+    f32x4 ac[RT], bc[CT];
+    stage_load(0);
+    load_b(0, 0, bc);
+    stage_store();
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) ac[rt] = *reinterpret_cast<const f32x4*>(a_ptr[rt]);
+
+    for (int cc = 0; cc < ncc; ++cc) {
+        const bool more = cc + 1 < ncc;
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+            f32x4 an[RT], bn[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) bn[ct] = bc[ct];
+            if (tap + 1 < T) {
+                load_b(cc, tap + 1, bn);
+                const int ky = (tap + 1) / KS, kx = (tap + 1) % KS;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    an[rt] = *reinterpret_cast<const f32x4*>(a_ptr[rt] + ky * wp_f + kx * PITCH);
+            } else if (more) {
+                load_b(cc + 1, 0, bn);
+            }
+            if (tap == T - 2 && more) stage_load(cc + 1);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt][j], bc[ct][j], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) bc[ct] = bn[ct];
+            if (tap + 1 < T) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) ac[rt] = an[rt];
+            } else if (more) {
+                __syncthreads();               // every wave is past its last read of this chunk's halo
+                stage_store();
+                __syncthreads();
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) ac[rt] = *reinterpret_cast<const f32x4*>(a_ptr[rt]);
+            }
+        }
+    }
+
+    // epilogue: identical to igemm_fwd_kernel's un-split path (C/D map of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg)
+    const int N = g.Cout;
+    float csum[CT], csq[CT], bias_v[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        csum[ct] = 0.f; csq[ct] = 0.f;
+        const int col = n0 + wcol + ct * 16 + lr;
+        bias_v[ct] = (e.bias && col < N) ? e.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wrow + rt * 16 + q * 4 + r;
+            if (row >= g.M) continue;
+            const size_t rbase = (size_t)row * N;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int col = n0 + wcol + ct * 16 + lr;
+                if (col >= N) continue;
+                float v = acc[rt][ct][r] + bias_v[ct];
+                if (e.relu) v = fmaxf(v, 0.f);
+                const size_t off = rbase + col;
+                if (e.dropout) {
+                    uint32_t u24 = fmix32(e.drop_prefix ^ (uint32_t)((size_t)row * N + col)) >> 8;
+                    v = (u24 >= e.drop_thr) ? v * e.drop_scale : 0.f;
+                }
+                if (e.mask) v = (e.mask[off] > 0.f) ? v * e.mask_scale : 0.f;
+                if (e.accumulate) v += Y[off];
+                Y[off] = v;
+                csum[ct] += v;
+                csq[ct] += v * v;
+            }
+        }
+    }
+    if (e.stats) {
+        __syncthreads();                       // the halo image is dead: reuse it for the cross-wave column sums
+        float* red = halo;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            csum[ct] += __shfl_xor(csum[ct], 16, 64);
+            csq[ct] += __shfl_xor(csq[ct], 16, 64);
+            csum[ct] += __shfl_xor(csum[ct], 32, 64);
+            csq[ct] += __shfl_xor(csq[ct], 32, 64);
+            if (q == 0) {
+                const int c = wcol + ct * 16 + lr;
+                red[((wave / WN) * BN + c) * 2] = csum[ct];
+                red[((wave / WN) * BN + c) * 2 + 1] = csq[ct];
+            }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < N) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { a += red[(w * BN + t) * 2]; b += red[(w * BN + t) * 2 + 1]; }
+            e.stats[((size_t)mtile * 2) * N + n0 + t] = a;
+            e.stats[((size_t)mtile * 2 + 1) * N + n0 + t] = b;
+        }
+    }
+}
+
 // combine the split-K slabs in fixed order and apply the epilogue (VEC = 4 when N % 4 == 0)
 struct BalDev { int bm, bn, nt, chunks, L, segmax; };   // balanced K partition: tile shape, N tiles, chunks per tile, units per workgroup
 
@@ -926,9 +1155,35 @@ size_t igemm_splitk_workspace(const ConvGeom& g) {
 // by the launcher and by the host-only launch plan the parity-coverage tests read (igemm_fwd_plan)
 struct FwdChoice {
     int mode, bm, bn, splits, balanced_wgs, flags;
-    bool bk32_tile, use_dma, stats;
-    int code() const { return mode * 100000000 + bm * 100000 + bn * 100 + (bk32_tile ? 32 : 16); }
+    bool bk32_tile, use_dma, stats, halo;
+    int ks;
+    // the halo kernel carries its window size in the chunk-depth field
+    int code() const { return mode * 100000000 + bm * 100000 + bn * 100 + (halo ? ks : (bk32_tile ? 32 : 16)); }
 };
+
+// halo-tiled direct convolution (halo_fwd_kernel): geometry it accepts and the LDS image it needs
+static inline int halo_bm(int cout) { return cout >= 64 ? 128 : 256; }   // narrow layers: every wave still owns 64 pixels x 16 / 32 columns
+static bool halo_geometry(const ConvGeom& cg, HaloDev* hd, size_t* lds_bytes) {
+    const int ks = cg.KH, R = ks / 2;
+    if (cg.KH != cg.KW || (ks != 3 && ks != 5) || cg.stride != 1 || cg.OH != cg.H || cg.OW != cg.W) return false;
+    if (cg.pad_t != R || cg.pad_l != R || cg.Cin % 16 != 0) return false;
+    if (cg.Cout % 64 != 0 && cg.Cout != 32 && cg.Cout != 16) return false;
+    const int bm = halo_bm(cg.Cout);
+    const int wp = (cg.W + ks - 1 + 7) / 8 * 8;
+    // virtual rows a flat bm-pixel tile can span: its pixel rows, plus R gap rows per image boundary it crosses
+    const int span = (bm - 2 + cg.W) / cg.W + 1 + ((bm - 1) / (cg.H * cg.W) + 1) * R;
+    const int rows = span + 2 * R;
+    if (rows * wp * 4 > halo_nst(bm) * 256) return false;
+    const size_t lds = (size_t)rows * wp * 24 * sizeof(float);
+    if (lds > 64 * 1024) return false;
+    if (hd) {
+        hd->WP = wp; hd->rows_max = rows; hd->VH = cg.H + R;
+        fastdiv_init(wp, &hd->wp_magic, &hd->wp_shift);
+        fastdiv_init(cg.H + R, &hd->vh_magic, &hd->vh_shift);
+    }
+    if (lds_bytes) *lds_bytes = lds;
+    return true;
+}
 static FwdChoice choose_fwd(const ConvGeom& cg, const GemmEpilogue& ep, size_t ws_floats, bool want_stats, bool have_rowtab) {
     FwdChoice c;
     const int M = cg.M(), N = cg.Cout, K = cg.K();
@@ -956,8 +1211,25 @@ static FwdChoice choose_fwd(const ConvGeom& cg, const GemmEpilogue& ep, size_t w
     // (Measured, not adopted, round 3: the many-wave 128x64 grids on 32-deep chunks with a SINGLE LDS image -- the trick that
     // helped the <= 64-channel weight gradient: forward 114.5 vs 123.0 TFLOP/s on 64->64 k5 @101x40, dgrad 105.7 vs 114.1 on k3.)
     const int bk = c.bk32_tile ? 32 : 16;
+    // halo-tiled direct convolution for the un-split 128-row launches it accepts (default since round 3; CMOOP_HALO=0 restores
+    // the implicit GEMM everywhere).  Isolated forward / dgrad TFLOP/s, halo vs implicit GEMM (profiles/r03_halo_kernel_bench.txt):
+    // 64->64 k5 @101x40 137.5 vs 122.1, k3 113 / 122 vs 105 / 114; 64->64 k5 @51x20 132.6 vs 117; 128->64 k5 (dgrad of 64->128)
+    // 139.2 vs 122.9; 32->32 k5 @101x40 119.4 vs 110 (LDS-DMA tile), @51x20 107 vs 93; 16->16 k5 90.4 vs 66.7, k3 51 vs 46.
+    // The one shape it loses is 32->32 k3 @101x40 (78.7 vs 87.2: two halo refills of a 256-pixel tile per 576 MFMAs), excluded below.
+    // 128-column layers run as two 64-column workgroups per tile: alone the second round of workgroups has a ragged tail
+    // (128->128 k5 @51x20: 117 vs 130; a 128 x 128 halo tile did 136), in the job it is the better form (2 225 vs 2 195 vs
+    // 2 180 evals/h for 64-column halo / 128-column halo / implicit GEMM).
+    static const bool halo_env = [] { const char* v = std::getenv("CMOOP_HALO"); return !(v && v[0] == '0'); }();
+    c.ks = cg.KH;
+    c.halo = halo_env && (c.mode == GEMM_FP32 || c.mode == GEMM_FP32_DMA) && c.bm == 128 && c.splits == 1 && !c.balanced_wgs && ep.out_stride == 1 &&
+             halo_geometry(cg, nullptr, nullptr) && !(cg.Cout == 32 && cg.KH == 3 && cg.W > 20);
+    if (c.halo) {
+        c.mode = GEMM_FP32_HALO; c.use_dma = false;
+        c.bm = halo_bm(cg.Cout);
+        c.bn = std::min(cg.Cout, 64);
+    }
     c.flags = (c.splits > 1 ? GEMM_FLAG_SPLITK : 0) | (c.stats ? GEMM_FLAG_STATS : 0) | (c.balanced_wgs ? GEMM_FLAG_BALANCED : 0) |
-              ((have_rowtab && (cg.Cin % bk) == 0 && cg.KH * cg.KW <= 32) ? GEMM_FLAG_ROWTAB : 0);
+              ((!c.halo && have_rowtab && (cg.Cin % bk) == 0 && cg.KH * cg.KW <= 32) ? GEMM_FLAG_ROWTAB : 0);
     return c;
 }
 
@@ -991,6 +1263,33 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
     e.stats = ch.stats ? ep.stats : nullptr;
     if (e.stats) *stats_blocks = cdiv(g.M, bm);
     if (flags_out) *flags_out = ch.flags;
+    if (ch.halo) {
+        HaloDev hd;
+        size_t lds = 0;
+        CMOOP_REQUIRE(halo_geometry(cg, &hd, &lds), "halo kernel chosen for a geometry it does not accept");
+        const dim3 grid(cdiv(g.M, bm), cdiv(g.Cout, bn));
+#define CMOOP_HALO_LAUNCH(KS_, BM_, BN_, WM_)                                                                                        \
+        do {                                                                                                                 \
+            if (tm && tm->start && tm->ext) {                                                                                \
+                hipExtLaunchKernelGGL((halo_fwd_kernel<KS_, BM_, BN_, WM_>), grid, dim3(256), lds, s, tm->start, tm->stop, 0, X, Wt, Y, g, e, hd); \
+            } else {                                                                                                         \
+                if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));                                                \
+                hipLaunchKernelGGL((halo_fwd_kernel<KS_, BM_, BN_, WM_>), grid, dim3(256), lds, s, X, Wt, Y, g, e, hd);    \
+                if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));                                                 \
+            }                                                                                                                \
+        } while (0)
+#define CMOOP_HALO_KS(KS_)                                                                     \
+        do {                                                                                   \
+            if (bn == 64) CMOOP_HALO_LAUNCH(KS_, 128, 64, 2);                                  \
+            else if (bn == 32) CMOOP_HALO_LAUNCH(KS_, 256, 32, 4);                             \
+            else CMOOP_HALO_LAUNCH(KS_, 256, 16, 4);                                           \
+        } while (0)
+        if (cg.KH == 5) CMOOP_HALO_KS(5); else CMOOP_HALO_KS(3);
+#undef CMOOP_HALO_KS
+#undef CMOOP_HALO_LAUNCH
+        CMOOP_HIP(hipGetLastError());
+        return ch.code();
+    }
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \
     do {                                                                                      \
         if (mode == GEMM_BF16X3) launch_fwd_t<BM_, BN_, 32, WM_, GEMM_BF16X3>(X, Wt, Y, g, e, s, tm, splitk_ws, splits, balanced_wgs, rowtab, tab_rows);   \

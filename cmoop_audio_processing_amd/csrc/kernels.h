@@ -23,7 +23,8 @@ struct ConvGeom {
 
 // Arithmetic of the MFMA GEMM kernels.  GEMM_FP32 (exact v_mfma_f32_16x16x4_f32) is the product default;
 // the bf16 matrix-core modes are opt-in (cmoop_config.gemm_mode or CMOOP_GEMM_MODE=bf16x3|bf16), see gemm.hip.
-enum GemmMode { GEMM_DEFAULT = -1, GEMM_FP32 = 0, GEMM_FP32_DMA = 1 /* kernel-internal: fp32 with LDS-DMA operand loads */, GEMM_BF16X3 = 2, GEMM_BF16 = 3 };
+enum GemmMode { GEMM_DEFAULT = -1, GEMM_FP32 = 0, GEMM_FP32_DMA = 1 /* kernel-internal: fp32 with LDS-DMA operand loads */, GEMM_BF16X3 = 2, GEMM_BF16 = 3,
+                GEMM_FP32_HALO = 4 /* kernel-internal: fp32, halo-tiled direct convolution (halo_fwd_kernel) */ };
 int gemm_mode_default();   // CMOOP_GEMM_MODE, else GEMM_FP32
 
 struct GemmEpilogue {

@@ -36,4 +36,15 @@ PRODUCTION_CONVS = [
     (64, 26, 10, 32, 64, 3, 1),
     (37, 26, 10, 32, 64, 3, 1),
     (37, 26, 10, 64, 64, 3, 1),      # too few K chunks for the balanced partition: the uniform split-K path of the 128x64 tile
+    # halo-tiled direct convolution (halo_fwd_kernel): tiles that cross image boundaries (26x10 = 260, 13x5 = 65 pixels per
+    # image against 128-pixel tiles), several 64-column workgroups per tile, the inference batch
+    (256, 51, 20, 64, 64, 3, 1),
+    (256, 13, 5, 256, 512, 3, 1),
+    (64, 51, 20, 16, 32, 5, 1),      # 256 x 32 halo tile, one 16-channel chunk
+    (64, 51, 20, 32, 32, 3, 1),
+    # the skip projections at the inference batch: many-wave grids of the implicit GEMM's 128-row tiles
+    (256, 51, 20, 16, 32, 1, 2),
+    (256, 51, 20, 32, 64, 1, 2),
+    (256, 51, 20, 64, 128, 1, 2),
+    (256, 26, 10, 128, 256, 1, 2),
 ]

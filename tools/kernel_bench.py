@@ -27,7 +27,7 @@ def main():
     L = _lib.lib()
     print(f"{'B,H,W,Cin,Cout,KS':28s} {'GFLOP':>8s} | " + " | ".join(f"{m:>7s} ms   TF/s" for m in ("fwd", "dgrad", "wgrad")))
     for (B, H, W, Cin, Cout, KS) in SHAPES:
-        if only and only not in f"{Cin},{Cout},{KS}":
+        if only and not any(o in f"{Cin},{Cout},{KS}" for o in only.split("|")):   # "64,64,|128,128,5": substrings of "Cin,Cout,KS"
             continue
         x = torch.randn((B, H, W, Cin), device="cuda")
         w = torch.randn((Cout, KS, KS, Cin), device="cuda") * 0.05
