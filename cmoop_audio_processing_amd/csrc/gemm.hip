@@ -172,6 +172,7 @@ std::string gemm_kernel_name(int cls, int code) {
     }
     // launch_igemm_wgrad's code: mode * 10^7 + (64-row chunks ? 10^6 : 0) + BCO * 1000 + BKI
     const int mode = code / 10000000, mc = (code / 1000000) % 10 ? 64 : 32, c = code % 1000000;
+    if (mode == GEMM_FP32_HALO) return "halo_wgrad_kernel<" + std::to_string(c / 1000) + ", " + std::to_string(c % 1000) + ">";
     const std::string tile = std::to_string(c / 1000) + ", " + std::to_string(c % 1000);
     return mode == GEMM_FP32 ? "igemm_wgrad_kernel<" + tile + ", " + std::to_string(mc) + ">"
                              : "igemm_wgrad_bf16_kernel<" + tile + ", " + (mode == GEMM_BF16X3 ? "3" : "1") + ">";
@@ -1268,6 +1269,19 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
         size_t lds = 0;
         CMOOP_REQUIRE(halo_geometry(cg, &hd, &lds), "halo kernel chosen for a geometry it does not accept");
         const dim3 grid(cdiv(g.M, bm), cdiv(g.Cout, bn));
+        // Workgroups per CU: the kernel's registers allow three, its LDS image usually too.  A grid of one to three rounds
+        // is quantised by the slot count -- 1 020 workgroups (128->128 @51x20 as two 64-column halves) are 1.33 rounds of 768
+        // slots but 1.99 rounds of 512 -- so the LDS request is padded past a third of the CU's 160 KiB when two per CU
+        // fill their last round better (CMOOP_HALO_OCC=2 / 3 forces either).  Isolated: 128->128 k5 @51x20 116 -> 140.8 TFLOP/s,
+        // k3 106 -> 124, 64->128 k5 113 -> 133; grids of more than two rounds keep three per CU (64->64 k5 @101x40, 2 020
+        // workgroups: 137.5 vs 133.7 with two).
+        {
+            static const int occ_env = [] { const char* v = std::getenv("CMOOP_HALO_OCC"); return v ? std::atoi(v) : 0; }();
+            const long wgs = (long)grid.x * grid.y;
+            auto fill = [&](long slots) { return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots); };
+            const bool two = occ_env == 2 || (occ_env != 3 && lds <= 53 * 1024 && wgs <= 1536 && fill(512) > fill(768) + 0.05);
+            if (two) lds = std::max(lds, (size_t)55 * 1024);
+        }
 #define CMOOP_HALO_LAUNCH(KS_, BM_, BN_, WM_)                                                                                        \
         do {                                                                                                                 \
             if (tm && tm->start && tm->ext) {                                                                                \
@@ -1575,6 +1589,193 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------
+// Halo-tiled weight gradient on the fp32 MFMA (stride 1, SAME, odd square window, W = 40 or 20):
+//   dWt[co][ky][kx][ci] = sum over pixels dY[b][y][x][co] * X[b][y + ky - R][x + kx - R][ci]
+// The implicit-GEMM form above re-gathers the input once per filter tap and re-reads dY once per 64- or 128-wide K tile
+// (13 x for 64->64 k5), with ~110 non-MFMA instructions per 64 MFMAs.  Here a workgroup owns a 64-channel dY tile, a
+// 16-channel input tile and ALL KS*KS taps (100 accumulator registers per lane for k5) over a range of image rows, and
+// walks it one image row per chunk: the KS input rows a chunk needs live in a ring of KS + 1 rows in LDS, so each new
+// chunk stages ONE new input row (W + KS - 1 pixels x 16 channels) and one dY row -- every input row is fetched once per
+// workgroup instead of once per tap.  The MFMA reduction index is the pixel: fragments are read pixel-major with
+// ds_read_b32 (16 consecutive channels x 4 pixels per wave instruction: conflict-free), the tap's column shift and the
+// step's pixel offset are ds_read immediates, the tap's row is a ring-slot base added once per chunk.
+// Waves: every wave holds all four 16-channel dY fragments of a step and T / 4 taps (6 of 25, 2 of 9); the last tap is
+// split by dY tile over the four waves, so all waves issue the same 4 T/4 + 1 MFMAs per step.
+// grid = (Cin / 16, Cout / 64, S row slices); slice z covers image rows [z rps, (z+1) rps) of the flattened (b, y) axis and
+// writes its partial sums to P[z] (same slab layout as igemm_wgrad_kernel: the optimiser launch sums them in fixed order).
+// ---------------------------------------------------------------------------
+template <int KS, int STEPS>   // STEPS = W / 4 MFMA steps per image row
+__global__ __launch_bounds__(256, 2) void halo_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                            float* __restrict__ P, GeomDev g, int rows_per_slice,
+                                                            float* __restrict__ Pbias, size_t slab_stride) {
+    constexpr int R = KS / 2, T = KS * KS, NR = KS + 1, W = STEPS * 4, WPX = W + 2 * R;
+    constexpr int TPW = T / 4;                 // whole taps per wave; tap T - 1 is shared
+    static_assert(T % 4 == 1, "3x3 and 5x5 windows");
+    constexpr int LDY = 80;                    // dY row pitch in LDS: 64 channels + 16 (== 16 mod 64 banks)
+    constexpr int XROW = WPX * 16;             // floats per ring row
+    constexpr int YP = (W * 16 + 255) / 256;   // dY float4 per thread and row
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Xs = lds;                     // [NR][WPX][16]
+    float* const Ys = lds + NR * XROW;         // [2][W][LDY]
+
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15, q = lane >> 4;
+    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 64, bz = blockIdx.z;
+    const int rows_tot = g.B * g.H;
+    const int r0 = min(rows_tot, bz * rows_per_slice), r1 = min(rows_tot, r0 + rows_per_slice);
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X), 0, (int)((uint32_t)g.B * g.H * g.W << g.cshift) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY), 0, g.M * g.Cout * 4, 0x00020000);
+    // staging roles: thread t < 4 WPX fetches channels 4 (t & 3).. of halo pixel t >> 2 of an input row;
+    // dY slot i = t + 256 p is channels 4 (i & 15).. of pixel i >> 4
+    const int hx = t >> 2, xj = t & 3;
+    const bool x_thread = t < 4 * WPX;
+    const uint32_t x_voff = (x_thread && hx >= R && hx < W + R) ? (uint32_t)((((hx - R) << g.cshift) + ci0 + 4 * xj) * 4) : 0xFFFFFFFFu;
+    float* const x_dst = Xs + hx * 16 + 4 * xj;
+    uint32_t y_voff[YP];
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+        const int i = t + 256 * p;
+        y_voff[p] = i < W * 16 ? (uint32_t)(((i >> 4) * g.Cout + co0 + 4 * (i & 15)) * 4) : 0xFFFFFFFFu;
+    }
+    float* const y_dst = Ys + (t >> 4) * LDY + 4 * (t & 15);      // + p * 16 * LDY (+ buffer)
+    auto load_x = [&](int b, int yy) {   // input row yy of image b (zeros outside the image)
+        const bool ok = yy >= 0 && yy < g.H;
+        const int soff = ok ? (int)((uint32_t)((b * g.H + yy) * g.W << g.cshift) * 4u) : 0;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(ok ? x_voff : 0xFFFFFFFFu), soff, 0));
+    };
+    auto load_y = [&](int b, int y, f32x4 (&ry)[YP]) {
+        const int soff = (int)((uint32_t)((b * g.H + y) * g.W) * (uint32_t)g.Cout * 4u);
+#pragma unroll
+        for (int p = 0; p < YP; ++p)
+            ry[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, (int)y_voff[p], soff, 0));
+    };
+    auto store_y = [&](int buf, const f32x4 (&ry)[YP]) {
+#pragma unroll
+        for (int p = 0; p < YP; ++p)
+            if (t + 256 * p < W * 16) *reinterpret_cast<f32x4*>(y_dst + buf * (W * LDY) + p * 16 * LDY) = ry[p];
+    };
+    auto slot_of = [&](int yy) { return (yy + NR) % NR; };          // yy >= -R
+
+    // this wave's taps: TPW whole taps starting at wave * TPW, plus dY tile `wave` of tap T - 1
+    int tap_ky[TPW + 1], tap_kx[TPW + 1];
+#pragma unroll
+    for (int i = 0; i <= TPW; ++i) {
+        const int tap = i < TPW ? wave * TPW + i : T - 1;
+        tap_ky[i] = tap / KS; tap_kx[i] = tap - tap_ky[i] * KS;
+    }
+    const float* const a_base = Ys + q * LDY + lr;                  // + buf, + 4 st rows, + 16 c2
+    const float* const b_base = Xs + q * 16 + lr;                   // + slot row, + (4 st + kx) pixels
+
+    f32x4 acc[4][TPW], accl = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[c2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = Pbias != nullptr && blockIdx.x == 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    int r = r0;
+    while (r < r1) {
+        // one segment: rows [ys, yend) of image b (a slice may run over several images)
+        const int b = r / g.H, ys = r - b * g.H;
+        const int yend = min(g.H, ys + (r1 - r));
+        f32x4 ry[YP];
+        {
+            f32x4 px[KS];
+#pragma unroll
+            for (int d = 0; d < KS; ++d) px[d] = load_x(b, ys - R + d);
+            load_y(b, ys, ry);
+            __syncthreads();                      // the previous segment's last reads
+            if (x_thread) {
+#pragma unroll
+                for (int d = 0; d < KS; ++d) *reinterpret_cast<f32x4*>(x_dst + slot_of(ys - R + d) * XROW) = px[d];
+            }
+            store_y(0, ry);
+            if (do_bias) {
+#pragma unroll
+                for (int p = 0; p < YP; ++p) bsum += ry[p];
+            }
+            __syncthreads();
+        }
+        for (int y = ys; y < yend; ++y) {
+            const int buf = (y - ys) & 1;
+            const bool more = y + 1 < yend;
+            f32x4 rx = {0.f, 0.f, 0.f, 0.f};
+            if (more) {
+                rx = load_x(b, y + 1 + R);
+                load_y(b, y + 1, ry);
+            }
+            const float* bp[TPW + 1];
+#pragma unroll
+            for (int i = 0; i <= TPW; ++i) bp[i] = b_base + slot_of(y + tap_ky[i] - R) * XROW + tap_kx[i] * 16;
+            const float* const ap = a_base + buf * (W * LDY);
+            const float* const apl = ap + wave * 16;
+            float a[2][4], al[2], bt[2][TPW + 1];
+            auto read_frags = [&](int st, int set) {
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) a[set][c2] = ap[st * 4 * LDY + c2 * 16];
+                al[set] = apl[st * 4 * LDY];
+#pragma unroll
+                for (int i = 0; i <= TPW; ++i) bt[set][i] = bp[i][st * 64];
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                if (st + 1 < STEPS) read_frags(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; ++c2)
+                        acc[c2][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1][c2], bt[st & 1][i], acc[c2][i], 0, 0, 0);
+                accl = __builtin_amdgcn_mfma_f32_16x16x4f32(al[st & 1], bt[st & 1][TPW], accl, 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (more) {
+                // the ring slot of row y + 1 + R held row y - R - 1, last read in chunk y - 1; dY buffer buf ^ 1 likewise
+                if (x_thread) *reinterpret_cast<f32x4*>(x_dst + slot_of(y + 1 + R) * XROW) = rx;
+                store_y(buf ^ 1, ry);
+                if (do_bias) {
+#pragma unroll
+                    for (int p = 0; p < YP; ++p) bsum += ry[p];
+                }
+            }
+            __syncthreads();
+        }
+        r += yend - ys;
+    }
+
+    if (do_bias) {   // fixed-order reduction over the 16 threads that share a channel quad
+        float* red = lds;
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&red[4 * t]) = bsum;
+        __syncthreads();
+        if (t < 64) {
+            const int q4 = t >> 2, j = t & 3;
+            float sacc = 0.f;
+            for (int rr = 0; rr < 16; ++rr) sacc += red[4 * (rr * 16 + q4) + j];
+            Pbias[(size_t)bz * slab_stride + co0 + t] = sacc;
+        }
+    }
+    float* Pout = P + (size_t)bz * slab_stride;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kcol = ((wave * TPW + i) << g.cshift) + ci0 + lr;
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                Pout[(size_t)(co0 + c2 * 16 + q * 4 + rr) * g.K + kcol] = acc[c2][i][rr];
+    }
+    {
+        const int kcol = ((T - 1) << g.cshift) + ci0 + lr;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Pout[(size_t)(co0 + wave * 16 + q * 4 + rr) * g.K + kcol] = accl[rr];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // weight-gradient kernel on the bf16 matrix core (GEMM_BF16X3: NP = 3 exact-split planes; GEMM_BF16: NP = 1).
 // Same grid / slices / partial layout as igemm_wgrad_kernel.  The reduction index of the MFMA is the pixel row m,
 // but both operands arrive m-major (dY[m][co], im2col(X)[m][k]), so the transposition happens on the way into
@@ -1746,7 +1947,30 @@ static bool wgrad_xcd_grouped() {
     return v;
 }
 
+// halo-tiled weight gradient (halo_wgrad_kernel): geometry it accepts
+static bool halo_wgrad_geometry(const ConvGeom& cg) {
+    // default since round 3 (CMOOP_HALO_WGRAD=0 restores the implicit GEMM).  Isolated TFLOP/s, halo vs implicit GEMM: 64->64 k5 @101x40
+    // 137.4 vs 113, k3 120.6 vs 99; 64->64 k5 @51x20 122 vs 97, k3 107 vs 87; 64->128 k5 129 vs 121, k3 117 vs 104; 128->128 @51x20
+    // 131.6 vs 130.6 (k3 equal); the pop-40 job 2 254.6 vs 2 222.3 evals/h.
+    static const bool on = [] { const char* v = std::getenv("CMOOP_HALO_WGRAD"); return !(v && v[0] == '0'); }();
+    const int ks = cg.KH, R = ks / 2;
+    return on && resolve_mode(GEMM_DEFAULT) == GEMM_FP32 && cg.KH == cg.KW && (ks == 3 || ks == 5) && cg.stride == 1 &&
+           cg.OH == cg.H && cg.OW == cg.W && cg.pad_t == R && cg.pad_l == R && (cg.W == 40 || cg.W == 20) &&
+           cg.Cin % 16 == 0 && cg.Cout % 64 == 0 && (cg.Cin / 16) * (cg.Cout / 64) <= 256;
+}
+// its slice count: one round of 512 workgroups (two per CU) whenever the slab budget and the row count allow
+static int halo_wgrad_slices(const ConvGeom& g) {
+    const int tiles = (g.Cin / 16) * (g.Cout / 64), rows = g.B * g.H;
+    int S = std::max(1, 512 / tiles);
+    const int64_t nk = (int64_t)g.Cout * g.K();
+    const int cap = (int)std::max<int64_t>(1, (16ll << 20) / std::max<int64_t>(nk, 1));     // <= ~16M slab floats
+    S = std::min(S, cap);
+    S = std::min(S, std::max(1, rows / 8));                                                 // >= 8 image rows per slice
+    return S;
+}
+
 int wgrad_slices(const ConvGeom& g) {
+    if (halo_wgrad_geometry(g)) return halo_wgrad_slices(g);
     const int M = g.M(), K = g.K(), N = g.Cout;
     const int bco = wgrad_bco(N);
     const int tiles = cdiv(K, wgrad_bki(M, N, K)) * cdiv(N, bco);
@@ -1811,6 +2035,10 @@ int igemm_wgrad_plan(const ConvGeom& g, int S, int mode_req, bool have_rowtab, i
     int mode = (N % 4 == 0) ? resolve_mode(mode_req) : (int)GEMM_FP32;
     if (mode == GEMM_BF16X3 && bco < 128) mode = GEMM_FP32;
     const bool rt = have_rowtab && g.KH * g.KW <= 32;
+    if (mode == GEMM_FP32 && halo_wgrad_geometry(g)) {
+        if (flags_out) *flags_out = S > 1 ? GEMM_FLAG_SLABS : 0;
+        return GEMM_FP32_HALO * 10000000 + g.KH * 1000 + g.W / 4;
+    }
     if (flags_out) *flags_out = ((rt && mode == GEMM_FP32 && (N & 3) == 0) ? GEMM_FLAG_ROWTAB : 0) | (S > 1 ? GEMM_FLAG_SLABS : 0);
     return mode * 10000000 + (wgrad_mc64(rt && (N & 3) == 0, mode, bco) ? 1000000 : 0) + bco * 1000 + bki;
 }
@@ -1832,6 +2060,34 @@ int launch_igemm_wgrad(const float* X, const float* dY, float* P, const ConvGeom
     // few MFMAs per element to hide it (measured 58 vs 73 TFLOP/s on 64->64 k5) -- the exact kernel is the better
     // fp32-accurate choice there.  (GEMM_BF16 must round everywhere to stay consistent with its definition.)
     if (mode == GEMM_BF16X3 && bco < 128) mode = GEMM_FP32;
+    if (mode == GEMM_FP32 && halo_wgrad_geometry(cg)) {
+        const int ks = cg.KH, steps = cg.W / 4;
+        const dim3 hgrid(cg.Cin / 16, cg.Cout / 64, S);
+        const int hrps = cdiv(cg.B * cg.H, S);
+        size_t lds = ((size_t)(ks + 1) * (cg.W + ks - 1) * 16 + 2 * (size_t)cg.W * 80) * sizeof(float);
+        // two workgroups per CU when that fills the last round better (see the forward halo launch)
+        {
+            const long wgs = (long)hgrid.x * hgrid.y * hgrid.z;
+            auto fill = [&](long slots) { return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots); };
+            if (wgs <= 1536 && fill(512) > fill(768) + 0.05) lds = std::max(lds, (size_t)55 * 1024);
+        }
+        if (flags_out) *flags_out = S > 1 ? GEMM_FLAG_SLABS : 0;
+#define CMOOP_HWG(KS_, ST_)                                                                                                  \
+        do {                                                                                                                 \
+            if (tm && tm->start && tm->ext) {                                                                                \
+                hipExtLaunchKernelGGL((halo_wgrad_kernel<KS_, ST_>), hgrid, dim3(256), lds, s, tm->start, tm->stop, 0, X, dY, P, g, hrps, Pbias, stride); \
+            } else {                                                                                                         \
+                if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));                                                \
+                hipLaunchKernelGGL((halo_wgrad_kernel<KS_, ST_>), hgrid, dim3(256), lds, s, X, dY, P, g, hrps, Pbias, stride); \
+                if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));                                                 \
+            }                                                                                                                \
+        } while (0)
+        if (ks == 5) { if (steps == 10) CMOOP_HWG(5, 10); else CMOOP_HWG(5, 5); }
+        else         { if (steps == 10) CMOOP_HWG(3, 10); else CMOOP_HWG(3, 5); }
+#undef CMOOP_HWG
+        CMOOP_HIP(hipGetLastError());
+        return GEMM_FP32_HALO * 10000000 + ks * 1000 + steps;
+    }
     dim3 grid(cdiv(g.K, bki), cdiv(N, bco), S);
     int gkt = 0, gct = 0;
     // (Measured, not adopted, round 3: row slices on the FASTEST grid axis, so that with round-robin dispatch every K tile of a
