@@ -752,10 +752,13 @@ struct HaloDev {
     uint32_t wp_magic, wp_shift, vh_magic, vh_shift;
 };
 __host__ __device__ constexpr int halo_nst(int bm) { return bm == 256 ? 11 : 9; }
+static bool halo_geometry(const ConvGeom& cg, HaloDev* hd, size_t* lds_bytes);
+static size_t halo_balanced_slab_floats(const ConvGeom& cg, int* L_out);
 
-template <int KS, int BM, int BN, int WM>   // BM x BN output tile (128 x 64; 256 x 32 / 256 x 16 for the narrow layers), WM x (4 / WM) waves
+template <int KS, int BM, int BN, int WM, bool BAL = false>   // BM x BN output tile (128 x 64; 256 x 32 / 256 x 16 for the narrow layers), WM x (4 / WM) waves
 __global__ __launch_bounds__(256, 2) void halo_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
-                                                          float* __restrict__ Y, GeomDev g, EpiDev e, HaloDev h) {
+                                                          float* __restrict__ Y, GeomDev g, EpiDev e, HaloDev h,
+                                                          float* __restrict__ slab) {
     constexpr int WN = 4 / WM, RT = BM / WM / 16, CT = BN / WN / 16, R = KS / 2, T = KS * KS;
     constexpr int PITCH = 24;      // floats per halo pixel: 16 channels + 8 pad
     constexpr int NST = halo_nst(BM);   // staged float4 per thread and channel chunk (host checks rows_max * WP * 4 <= NST * 256)
@@ -763,13 +766,41 @@ __global__ __launch_bounds__(256, 2) void halo_fwd_kernel(const float* __restric
     extern __shared__ __attribute__((aligned(16))) float halo[];
 
     const int t = threadIdx.x;
-    int mtile = blockIdx.x;
-    {   // XCD-aware tile order, as in igemm_fwd_kernel: neighbouring tiles share halo rows in one XCD's L2
+    const int ncc = g.Cin >> 4;
+    // BAL (under-filled grids: the 26x10 / 13x5 layers at the train batch): the launch's work is the tile-major sequence of
+    // (tile, channel chunk, kernel row) units -- KS taps of 16 channels each -- and workgroup w owns units [w L, (w+1) L): the
+    // same number for every workgroup whatever the tile count is against the chip's 512 slots.  A range is cut into pieces at
+    // tile boundaries; every piece writes its raw partial tile to slot (tile, seg) of the slab, seg counting the tile's pieces
+    // in unit order, and splitk_combine_kernel adds them in that order before the epilogue (as for igemm_fwd_kernel).
+    const int upt = ncc * KS;                                  // units per tile
+    int u = 0, uend = 1;
+    if constexpr (BAL) {
+        const int U = ((g.M + BM - 1) / BM) * ((g.Cout + BN - 1) / BN) * upt;
+        u = blockIdx.x * e.bal_L;
+        uend = min(U, u + e.bal_L);
+    }
+    while (u < uend) {
+    int mtile, ntile, c_lo = 0, c_hi = upt;
+    float* pslab = nullptr;
+    if constexpr (BAL) {
+        const int nt = (g.Cout + BN - 1) / BN;
+        const int t0 = u / upt;
+        c_lo = u - t0 * upt;
+        c_hi = min(upt, c_lo + (uend - u));
+        mtile = t0 / nt; ntile = t0 - mtile * nt;
+        const int seg = c_lo == 0 ? 0 : (int)blockIdx.x - (t0 * upt) / e.bal_L;
+        pslab = slab + ((size_t)t0 * e.bal_segmax + seg) * (BM * BN);
+        u += c_hi - c_lo;
+        __syncthreads();                                       // the previous piece's halo image is dead only now
+    } else {
+        u = uend;
+        mtile = blockIdx.x;
+        // XCD-aware tile order, as in igemm_fwd_kernel: neighbouring tiles share halo rows in one XCD's L2
         const int nwg = gridDim.x, xcd = mtile & 7, idx = mtile >> 3;
         const int qn = nwg >> 3, rn = nwg & 7;
         mtile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+        ntile = blockIdx.y;
     }
-    const int ntile = blockIdx.y;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
     const int wrow = (wave / WN) * (BM / WM), wcol = (wave % WN) * (BN / WN);
@@ -841,7 +872,72 @@ __global__ __launch_bounds__(256, 2) void halo_fwd_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int ncc = g.Cin >> 4;
+    if constexpr (BAL) {
+        // unit loop: unit c = (channel chunk c / KS, kernel row c % KS); the KS taps of a unit are unrolled (their column shift is
+        // a ds_read immediate), the kernel row is one address add per unit; B and A fragments run one tap ahead as below
+        int cc = c_lo / KS, ky = c_lo - cc * KS;
+        f32x4 ac[RT], bc[CT];
+        stage_load(cc);
+        load_b(cc, ky * KS, bc);
+        stage_store();
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) ac[rt] = *reinterpret_cast<const f32x4*>(a_ptr[rt] + ky * wp_f);
+        for (int c = c_lo; c < c_hi; ++c) {
+            const bool last_unit = c + 1 == c_hi, new_cc = ky == KS - 1;
+            const int nky = new_cc ? 0 : ky + 1, ncc2 = new_cc ? cc + 1 : cc;
+            if (new_cc && !last_unit) stage_load(cc + 1);
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                f32x4 an[RT], bn[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) bn[ct] = bc[ct];
+                if (kx + 1 < KS) {
+                    load_b(cc, ky * KS + kx + 1, bn);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        an[rt] = *reinterpret_cast<const f32x4*>(a_ptr[rt] + ky * wp_f + (kx + 1) * PITCH);
+                } else if (!last_unit) {
+                    load_b(ncc2, nky * KS, bn);
+                    if (!new_cc) {
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const f32x4*>(a_ptr[rt] + nky * wp_f);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt][j], bc[ct][j], acc[rt][ct], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) bc[ct] = bn[ct];
+                if (kx + 1 < KS || (!last_unit && !new_cc)) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) ac[rt] = an[rt];
+                } else if (!last_unit) {
+                    __syncthreads();           // every wave is past its last read of this chunk's halo
+                    stage_store();
+                    __syncthreads();
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) ac[rt] = *reinterpret_cast<const f32x4*>(a_ptr[rt]);
+                }
+            }
+            ky = nky; cc = ncc2;
+        }
+        // this piece's raw partial tile, [BM][BN] in its (tile, seg) slot of the slab
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    pslab[(wrow + rt * 16 + q * 4 + r) * BN + wcol + ct * 16 + lr] = acc[rt][ct][r];
+        continue;
+    } else {
     f32x4 ac[RT], bc[CT];
     stage_load(0);
     load_b(0, 0, bc);
@@ -889,6 +985,8 @@ __global__ __launch_bounds__(256, 2) void halo_fwd_kernel(const float* __restric
                 for (int rt = 0; rt < RT; ++rt) ac[rt] = *reinterpret_cast<const f32x4*>(a_ptr[rt]);
             }
         }
+    }
+
     }
 
     // epilogue: identical to igemm_fwd_kernel's un-split path (C/D map of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg)
@@ -950,6 +1048,7 @@ __global__ __launch_bounds__(256, 2) void halo_fwd_kernel(const float* __restric
             e.stats[((size_t)mtile * 2 + 1) * N + n0 + t] = b;
         }
     }
+    }   // piece loop
 }
 
 // combine the split-K slabs in fixed order and apply the epilogue (VEC = 4 when N % 4 == 0)
@@ -1149,7 +1248,25 @@ size_t igemm_splitk_workspace(const ConvGeom& g) {
     const long blocks = (long)cdiv(M, 128) * cdiv(N, bn_big);
     if (blocks >= 384) return 0;
     const int sp = std::min(32, cdiv(1024, (int)blocks));
-    return std::max((size_t)sp * M * N, balanced_slab_floats(M, N, g.K(), g.Cin % 32 == 0 ? 32 : 16, bn_big, nullptr));
+    return std::max(std::max((size_t)sp * M * N, balanced_slab_floats(M, N, g.K(), g.Cin % 32 == 0 ? 32 : 16, bn_big, nullptr)),
+                    halo_balanced_slab_floats(g, nullptr));
+}
+
+// balanced unit partition of the halo kernel on an under-filled grid (see halo_fwd_kernel): units per workgroup for one round
+// of 512 workgroups, slab floats it needs; 0 if the geometry does not qualify
+static size_t halo_balanced_slab_floats(const ConvGeom& cg, int* L_out) {
+    // default since round 3 (CMOOP_HALO_BAL=0 restores the implicit GEMM's balanced K partition).  Isolated forward / dgrad TFLOP/s,
+    // halo vs implicit GEMM: 256->256 k5 @26x10 133.3 / 134.1 vs 127.4 / 128.5, 512->512 k5 @13x5 132.2 vs 126.4, 128->256 k5 125.5 vs
+    // 119.6, 128->256 k3 @13x5 65.5 vs 48.8, the k3 layers +1..4 %; the pop-40 job 2 282.0 vs 2 258.3 evals/h.
+    static const bool on = [] { const char* v = std::getenv("CMOOP_HALO_BAL"); return !(v && v[0] == '0'); }();
+    if (!on || cg.Cout % 64 != 0 || !halo_geometry(cg, nullptr, nullptr)) return 0;
+    const long tiles = (long)cdiv(cg.M(), 128) * (cg.Cout / 64);
+    const int upt = (cg.Cin / 16) * cg.KH;
+    const long units = tiles * upt;
+    if (tiles >= 1024 || units < 512l * 2 * cg.KH) return 0;          // a filled grid runs un-split; at least two chunks' worth per workgroup
+    const int L = (int)((units + 511) / 512);
+    if (L_out) *L_out = L;
+    return (size_t)tiles * (cdiv(upt, L) + 1) * 128 * 64;
 }
 
 // tile / split / operand-path choice of a forward-type launch: pure host arithmetic on the geometry (no HIP call), shared
@@ -1157,7 +1274,7 @@ size_t igemm_splitk_workspace(const ConvGeom& g) {
 struct FwdChoice {
     int mode, bm, bn, splits, balanced_wgs, flags;
     bool bk32_tile, use_dma, stats, halo;
-    int ks;
+    int ks, halo_L;          // halo_L > 0: balanced unit partition of the halo kernel (units per workgroup)
     // the halo kernel carries its window size in the chunk-depth field
     int code() const { return mode * 100000000 + bm * 100000 + bn * 100 + (halo ? ks : (bk32_tile ? 32 : 16)); }
 };
@@ -1224,10 +1341,18 @@ static FwdChoice choose_fwd(const ConvGeom& cg, const GemmEpilogue& ep, size_t w
     c.ks = cg.KH;
     c.halo = halo_env && (c.mode == GEMM_FP32 || c.mode == GEMM_FP32_DMA) && c.bm == 128 && c.splits == 1 && !c.balanced_wgs && ep.out_stride == 1 &&
              halo_geometry(cg, nullptr, nullptr) && !(cg.Cout == 32 && cg.KH == 3 && cg.W > 20);
+    c.halo_L = 0;
     if (c.halo) {
         c.mode = GEMM_FP32_HALO; c.use_dma = false;
         c.bm = halo_bm(cg.Cout);
         c.bn = std::min(cg.Cout, 64);
+    } else if (halo_env && (c.mode == GEMM_FP32 || c.mode == GEMM_FP32_DMA) && c.bm == 128 && (c.splits > 1 || c.balanced_wgs) && ep.out_stride == 1) {
+        int L = 0;
+        const size_t need = halo_balanced_slab_floats(cg, &L);
+        if (need > 0 && need <= ws_floats) {
+            c.halo = true; c.halo_L = L; c.mode = GEMM_FP32_HALO; c.use_dma = false; c.stats = false;
+            c.bm = 128; c.bn = 64; c.splits = 1; c.balanced_wgs = 512;
+        }
     }
     c.flags = (c.splits > 1 ? GEMM_FLAG_SPLITK : 0) | (c.stats ? GEMM_FLAG_STATS : 0) | (c.balanced_wgs ? GEMM_FLAG_BALANCED : 0) |
               ((!c.halo && have_rowtab && (cg.Cin % bk) == 0 && cg.KH * cg.KW <= 32) ? GEMM_FLAG_ROWTAB : 0);
@@ -1268,7 +1393,15 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
         HaloDev hd;
         size_t lds = 0;
         CMOOP_REQUIRE(halo_geometry(cg, &hd, &lds), "halo kernel chosen for a geometry it does not accept");
-        const dim3 grid(cdiv(g.M, bm), cdiv(g.Cout, bn));
+        dim3 grid(cdiv(g.M, bm), cdiv(g.Cout, bn));
+        BalDev bal{bm, bn, cdiv(g.Cout, bn), (cg.Cin / 16) * cg.KH, ch.halo_L, 0};
+        if (ch.halo_L > 0) {
+            bal.segmax = cdiv(bal.chunks, bal.L) + 1;
+            e.bal_L = bal.L; e.bal_segmax = bal.segmax;
+            const long units = (long)grid.x * grid.y * bal.chunks;
+            grid = dim3((unsigned)((units + bal.L - 1) / bal.L), 1, 1);
+            lds = std::max(lds, (size_t)55 * 1024);                   // one round of two workgroups per CU
+        }
         // Workgroups per CU: the kernel's registers allow three, its LDS image usually too.  A grid of one to three rounds
         // is quantised by the slot count -- 1 020 workgroups (128->128 @51x20 as two 64-column halves) are 1.33 rounds of 768
         // slots but 1.99 rounds of 512 -- so the LDS request is padded past a third of the CU's 160 KiB when two per CU
@@ -1282,26 +1415,33 @@ int launch_igemm_fwd(const float* X, const float* Wt, float* Y, const ConvGeom& 
             const bool two = occ_env == 2 || (occ_env != 3 && lds <= 53 * 1024 && wgs <= 1536 && fill(512) > fill(768) + 0.05);
             if (two) lds = std::max(lds, (size_t)55 * 1024);
         }
-#define CMOOP_HALO_LAUNCH(KS_, BM_, BN_, WM_)                                                                                        \
+#define CMOOP_HALO_LAUNCH(KS_, BM_, BN_, WM_, BAL_)                                                                                        \
         do {                                                                                                                 \
             if (tm && tm->start && tm->ext) {                                                                                \
-                hipExtLaunchKernelGGL((halo_fwd_kernel<KS_, BM_, BN_, WM_>), grid, dim3(256), lds, s, tm->start, tm->stop, 0, X, Wt, Y, g, e, hd); \
+                hipExtLaunchKernelGGL((halo_fwd_kernel<KS_, BM_, BN_, WM_, BAL_>), grid, dim3(256), lds, s, tm->start, tm->stop, 0, X, Wt, Y, g, e, hd, splitk_ws); \
             } else {                                                                                                         \
                 if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->start, s));                                                \
-                hipLaunchKernelGGL((halo_fwd_kernel<KS_, BM_, BN_, WM_>), grid, dim3(256), lds, s, X, Wt, Y, g, e, hd);    \
+                hipLaunchKernelGGL((halo_fwd_kernel<KS_, BM_, BN_, WM_, BAL_>), grid, dim3(256), lds, s, X, Wt, Y, g, e, hd, splitk_ws);    \
                 if (tm && tm->start) CMOOP_HIP(hipEventRecord(tm->stop, s));                                                 \
             }                                                                                                                \
         } while (0)
 #define CMOOP_HALO_KS(KS_)                                                                     \
         do {                                                                                   \
-            if (bn == 64) CMOOP_HALO_LAUNCH(KS_, 128, 64, 2);                                  \
-            else if (bn == 32) CMOOP_HALO_LAUNCH(KS_, 256, 32, 4);                             \
-            else CMOOP_HALO_LAUNCH(KS_, 256, 16, 4);                                           \
+            if (ch.halo_L > 0) CMOOP_HALO_LAUNCH(KS_, 128, 64, 2, true);                       \
+            else if (bn == 64) CMOOP_HALO_LAUNCH(KS_, 128, 64, 2, false);                      \
+            else if (bn == 32) CMOOP_HALO_LAUNCH(KS_, 256, 32, 4, false);                      \
+            else CMOOP_HALO_LAUNCH(KS_, 256, 16, 4, false);                                    \
         } while (0)
         if (cg.KH == 5) CMOOP_HALO_KS(5); else CMOOP_HALO_KS(3);
 #undef CMOOP_HALO_KS
 #undef CMOOP_HALO_LAUNCH
         CMOOP_HIP(hipGetLastError());
+        if (ch.halo_L > 0) {     // fixed-order sum of every tile's pieces + the epilogue
+            const size_t total = (size_t)g.M * g.Cout;
+            const unsigned gridc = (unsigned)std::min<size_t>((total / 4 + 255) / 256, 4096);
+            hipLaunchKernelGGL(splitk_combine_kernel<4>, dim3(gridc), dim3(256), 0, s, splitk_ws, Y, g, e, 2, bal);
+            CMOOP_HIP(hipGetLastError());
+        }
         return ch.code();
     }
 #define CMOOP_FWD(BM_, BN_, WM_)                                                              \

@@ -586,11 +586,23 @@ def test_wgrad_workspace_partial_batches_advice_r1(B):
                 e_o32 = per_tensor_err(gene, 0, classes, o32.grads_flat(), o64.grads_flat())
                 worst = max(e_hip, key=e_hip.get)
                 print(f"B={b}: worst HIP-vs-fp64 {worst} {e_hip[worst]:.2e} (fp32 oracle vs fp64 there: {e_o32[worst]:.2e})")
+                # A flipped pool / ReLU decision moves a tensor of this BatchNorm gene by up to a few 1e-2 of its max on a few
+                # elements (either fp32 side draws them independently: tests/test_gpu_production_shapes.py, DESIGN section 2;
+                # observed here: 1.1e-2 on res0_conv1/kernel with the oracle at 2.0e-3) -- so the max-abs floor is the BatchNorm
+                # one (5e-2) and the corruption check is the relative L2 error per tensor: a slab written past the workspace or
+                # summed from stale memory is broad, >= 1e-1 and usually O(1).  The layer's kernels at exactly this batch are
+                # compared at 5e-5 in tests/_production_shapes.py (51, 51, 20, ...).
                 for name in e_hip:
-                    # 5e-3: a flipped pool / ReLU decision moves a tensor by ~1e-3 of its max (it happens on either side:
-                    # HIP 1.2e-3 with the fp32 oracle at 6e-6, and the reverse, were both observed); a slab written
-                    # past the workspace or summed from stale memory is >= 1e-2 and usually O(1)
-                    assert e_hip[name] <= max(5e-3, 5.0 * e_o32[name]), (name, e_hip[name], e_o32[name])
+                    assert e_hip[name] <= max(5e-2, 5.0 * e_o32[name]), (name, e_hip[name], e_o32[name])
+                g_hip, g_64, g_32 = net.get_grads().astype(np.float64), o64.grads_flat().astype(np.float64), o32.grads_flat().astype(np.float64)
+                off = 0
+                for (name, shape, role) in G.param_tensors(gene, 0, classes):
+                    n = int(np.prod(shape))
+                    if role == "kernel":
+                        ref = max(np.linalg.norm(g_64[off:off + n]), 1e-30)
+                        l_hip, l_o32 = np.linalg.norm(g_hip[off:off + n] - g_64[off:off + n]) / ref, np.linalg.norm(g_32[off:off + n] - g_64[off:off + n]) / ref
+                        assert l_hip <= max(1e-2, 5.0 * l_o32), (name, l_hip, l_o32)
+                    off += n
         lg, _ = net.train_metrics()          # summed loss of both steps: the second step ran on sane weights
         assert np.isfinite(lg)
         l_o, a_o, _ = o32.evaluate(X, y)

@@ -1,3 +1,3 @@
-bash tools/gpu_steps.sh h8 \
- "400 CMOOP_HALO_WGRAD=1 python -m pytest tests/test_gpu_production_shapes.py -x -q -m gpu -k 'through'" \
- "200 CMOOP_HALO_WGRAD=1 python tools/kernel_bench.py '64,64,|128,128,|64,128,'"
+bash tools/gpu_steps.sh h11 \
+ "500 bash tools/ab_bench.sh h11ab - CMOOP_HALO_BAL=1" \
+ "900 python -m pytest tests -x -q -m gpu"
