@@ -165,7 +165,8 @@ std::string gemm_kernel_name(int cls, int code) {
         const int mode = code / 100000000, c = code % 100000000;
         const int bm = c / 100000, bn = (c / 100) % 1000, bk = c % 100;
         if (mode == GEMM_FP32_HALO)
-            return "halo_fwd_kernel<" + std::to_string(bk) + ", " + std::to_string(bm) + ", " + std::to_string(bn) + ", " + (bn >= 64 ? "2>" : "4>");
+            return "halo_fwd_kernel<" + std::to_string(bk % 50) + ", " + std::to_string(bm) + ", " + std::to_string(bn) + ", " + (bn >= 64 ? "2, " : "4, ") +
+                   (bk >= 50 ? "true>" : "false>");      // the chunk-depth field carries the window size (+ 50: balanced unit partition)
         const int wm = (bm == bn) ? 2 : 4;   // wave layout of each instantiation (launch_igemm_fwd)
         return "igemm_fwd_kernel<" + std::to_string(bm) + ", " + std::to_string(bn) + ", " + std::to_string(bk) + ", " +
                std::to_string(wm) + ", " + std::to_string(mode) + ">";
@@ -1276,7 +1277,7 @@ struct FwdChoice {
     bool bk32_tile, use_dma, stats, halo;
     int ks, halo_L;          // halo_L > 0: balanced unit partition of the halo kernel (units per workgroup)
     // the halo kernel carries its window size in the chunk-depth field
-    int code() const { return mode * 100000000 + bm * 100000 + bn * 100 + (halo ? ks : (bk32_tile ? 32 : 16)); }
+    int code() const { return mode * 100000000 + bm * 100000 + bn * 100 + (halo ? ks + (halo_L > 0 ? 50 : 0) : (bk32_tile ? 32 : 16)); }
 };
 
 // halo-tiled direct convolution (halo_fwd_kernel): geometry it accepts and the LDS image it needs
@@ -1759,6 +1760,9 @@ __global__ __launch_bounds__(256, 2) void halo_wgrad_kernel(const float* __restr
     float* const Ys = lds + NR * XROW;         // [2][W][LDY]
 
     const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = lane & 15, q = lane >> 4;
+    // (Measured, not adopted: slices on the fastest grid axis, so that the input-channel tiles of one slice -- which read the same dY
+    // rows -- land on one XCD's L2: 137.8 vs 137.6 TFLOP/s on 64->64 k5 @101x40, no change on any shape.  The kernel streams: L2 hit
+    // rate 0.005, fabric reads 389 MB against 197 MB algorithmic, at 0.86 of the SIMD cycles in MFMA.)
     const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 64, bz = blockIdx.z;
     const int rows_tot = g.B * g.H;
     const int r0 = min(rows_tot, bz * rows_per_slice), r1 = min(rows_tot, r0 + rows_per_slice);
@@ -1812,7 +1816,7 @@ __global__ __launch_bounds__(256, 2) void halo_wgrad_kernel(const float* __restr
     for (int c2 = 0; c2 < 4; ++c2)
 #pragma unroll
         for (int i = 0; i < TPW; ++i) acc[c2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = Pbias != nullptr && blockIdx.x == 0;
+    const bool do_bias = Pbias != nullptr && ci0 == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
     int r = r0;

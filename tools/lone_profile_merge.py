@@ -45,7 +45,7 @@ def main():
     print(f"all MFMA instantiations together: {tot_fl / tot_ns:.1f} TFLOP/s over their summed trace time = {tot_fl / tot_ns / PEAK:.3f} of peak")
     print("non-MFMA kernels by trace time:")
     for k in trace["kernels"]:
-        if not k["name"].startswith("igemm_") and k["pct"] >= 0.3:
+        if not k["name"].startswith(("igemm_", "halo_")) and k["pct"] >= 0.3:
             print(f"   {k['pct']:5.2f} %  {k['calls']:6d} x {k['avg_us']:8.1f} us  {k['name']}")
 
 

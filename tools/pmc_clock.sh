@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(out, "raw", "**", "*counter_collection.csv"), re
     for r in csv.DictReader(open(f)):
         cols = list(r.keys())
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cmoop::", "")
-        if "igemm" not in k:
+        if "igemm" not in k and "halo_" not in k:
             continue
         key = (k, shape, r.get("Dispatch_Id", ""))
         rows[key][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("${OUT}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if "igemm" not in k: continue
+        if "igemm" not in k and "halo_" not in k: continue
         key = (k, r["Grid_Size"])
         a = agg[key][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for key in sorted(agg):

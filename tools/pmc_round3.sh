@@ -33,9 +33,9 @@ for f in glob.glob(os.path.join(out, "raw", "**", "*counter_collection.csv"), re
     shape = passname.split("_", 1)[1] if "_" in passname else ""
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cmoop::", "")
-        if not ("igemm" in k or "logmel" in k):
+        if not ("igemm" in k or "halo_" in k or "logmel" in k):
             continue
-        key = (k, r["Grid_Size"], shape if "igemm" in k else "")
+        key = (k, r["Grid_Size"], shape if ("igemm" in k or "halo_" in k) else "")
         a = agg[key][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 res = []

@@ -35,7 +35,7 @@ def main():
             p[1] += d
             p[2] = min(p[2], d)
             p[3] = max(p[3], d)
-            mf = 1 if nm.startswith("igemm_") else 0
+            mf = 1 if nm.startswith(("igemm_", "halo_")) else 0
             events.append((s, 1, mf))
             events.append((e, -1, -mf))
     events.sort()
@@ -56,7 +56,7 @@ def main():
         last = t
     span = (events[-1][0] - events[0][0]) if events else 0
     tot = sum(p[1] for p in per.values())
-    mfma_tot = sum(p[1] for k, p in per.items() if k.startswith("igemm_"))
+    mfma_tot = sum(p[1] for k, p in per.items() if k.startswith(("igemm_", "halo_")))
     rows = sorted(per.items(), key=lambda kv: -kv[1][1])
     summary = {
         "dispatches": sum(p[0] for p in per.values()),
