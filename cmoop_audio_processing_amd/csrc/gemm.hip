@@ -979,6 +979,13 @@ __global__ __launch_bounds__(256, 2) void halo_fwd_kernel(const float* __restric
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) ac[rt] = an[rt];
             } else if (more) {
+                // (Measured, not adopted: the refill IN FRONT of the last tap's MFMAs -- LDS-counter-only barriers, staged rows
+                // fetched five taps ahead -- so that stores, barrier and the next chunk's first fragment reads overlap that burst:
+                // no change on any shape (64->64 k3 @101x40 119.5 / 120.6 vs 119.4 / 123.4 TFLOP/s, k5 137.3 vs 138.1): the
+                // co-resident workgroups already cover the refill.  Bisect of the isolated launch (64->64 @101x40, 2 020 tiles):
+                // one channel chunk costs 0.090 ms (k5) / 0.035 ms (k3) = 147 / 136 TFLOP/s for the main loop alone; the prologue
+                // 8-10 us per launch; the epilogue 17-18 us = the 66 MB output written at 3.7 TB/s in bursts, because the
+                // workgroups of a round finish together -- 5 % of a k5 launch, 10 % of a k3 launch when it runs alone.)
                 __syncthreads();               // every wave is past its last read of this chunk's halo
                 stage_store();
                 __syncthreads();

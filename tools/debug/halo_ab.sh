@@ -1,4 +1,3 @@
-bash tools/gpu_steps.sh h13 \
- "200 python tools/kernel_bench.py '64,64,|128,128,|64,128,'" \
- "200 CMOOP_HALO_WGRAD_SWAP=1 python tools/kernel_bench.py '64,64,|128,128,|64,128,'" \
- "300 CMOOP_HALO_WGRAD_SWAP=1 python -m pytest tests/test_gpu_production_shapes.py -x -q -m gpu -k through"
+bash tools/gpu_steps.sh h16 \
+ "200 CMOOP_HALO_DBG=2 python tools/kernel_bench.py '64,64,'" \
+ "200 CMOOP_HALO_DBG=3 python tools/kernel_bench.py '64,64,'"
