@@ -105,13 +105,12 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict_
 }
 
 // dX[m][k] = sum_n dY[m][n] * W[n][k], optionally masked: mask[m][k] > 0 ? v * scale : 0
-__global__ __launch_bounds__(256) void dense_dgrad_kernel(const float* __restrict__ dY, const float* __restrict__ W,
-                                                          float* __restrict__ dX, int M, int N, int K,
-                                                          const float* __restrict__ mask, float scale, int bf16) {
-    __shared__ __attribute__((aligned(16))) float red[3 * 256];
+__device__ __forceinline__ void dense_dgrad_body(const int bid, float* red, const float* __restrict__ dY, const float* __restrict__ W,
+                                                 float* __restrict__ dX, int M, int N, int K,
+                                                 const float* __restrict__ mask, float scale, int bf16) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
     const int k_tiles = K >> 4;
-    const int m0 = (blockIdx.x / k_tiles) * 16, k0 = (blockIdx.x % k_tiles) * 16;
+    const int m0 = (bid / k_tiles) * 16, k0 = (bid % k_tiles) * 16;
     const bool aok = m0 + lr < M;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bool rb = bf16 != 0;
@@ -143,13 +142,19 @@ __global__ __launch_bounds__(256) void dense_dgrad_kernel(const float* __restric
 }
 
 // dW[n][k] = sum_m dY[m][n] * X[m][k];  dB[n] = sum_m dY[m][n] (by the k-tile-0 workgroups)
-__global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
-                                                          float* __restrict__ dW, float* __restrict__ dB, int M, int N,
-                                                          int K, int bf16) {
+__global__ __launch_bounds__(256) void dense_dgrad_kernel(const float* __restrict__ dY, const float* __restrict__ W,
+                                                          float* __restrict__ dX, int M, int N, int K,
+                                                          const float* __restrict__ mask, float scale, int bf16) {
     __shared__ __attribute__((aligned(16))) float red[3 * 256];
+    dense_dgrad_body(blockIdx.x, red, dY, W, dX, M, N, K, mask, scale, bf16);
+}
+
+// dW[n][k] = sum_m dY[m][n] * X[m][k];  dB[n] = sum_m dY[m][n] (by the k-tile-0 workgroups)
+__device__ __forceinline__ void dense_wgrad_body(const int bid, float* red, const float* __restrict__ X, const float* __restrict__ dY,
+                                                 float* __restrict__ dW, float* __restrict__ dB, int M, int N, int K, int bf16) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
     const int k_tiles = K >> 4;
-    const int n0 = (blockIdx.x / k_tiles) * 16, k0 = (blockIdx.x % k_tiles) * 16;
+    const int n0 = (bid / k_tiles) * 16, k0 = (bid % k_tiles) * 16;
     const bool nok = n0 + lr < N;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bool rb = bf16 != 0;
@@ -179,6 +184,24 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restric
         for (int m = 0; m < M; ++m) s += dY[(size_t)m * N + n0 + lane];
         dB[n0 + lane] = s;
     }
+}
+
+__global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                          float* __restrict__ dW, float* __restrict__ dB, int M, int N,
+                                                          int K, int bf16) {
+    __shared__ __attribute__((aligned(16))) float red[3 * 256];
+    dense_wgrad_body(blockIdx.x, red, X, dY, dW, dB, M, N, K, bf16);
+}
+
+// weight gradient and data gradient of one dense layer in ONE launch (both read dY; the first wgrad_blocks workgroups are the
+// weight-gradient tiles, the rest the data-gradient tiles): the same two bodies, bit-identical results, one dispatch fewer per layer
+__global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                        const float* __restrict__ W, float* __restrict__ dW, float* __restrict__ dB,
+                                                        float* __restrict__ dX, int M, int N, int K, const float* __restrict__ mask,
+                                                        float scale, int bf16, int wgrad_blocks) {
+    __shared__ __attribute__((aligned(16))) float red[3 * 256];
+    if ((int)blockIdx.x < wgrad_blocks) dense_wgrad_body(blockIdx.x, red, X, dY, dW, dB, M, N, K, bf16);
+    else dense_dgrad_body((int)blockIdx.x - wgrad_blocks, red, dY, W, dX, M, N, K, mask, scale, bf16);
 }
 
 static const float* dense_zero_page() {
@@ -223,6 +246,15 @@ void launch_dense_dgrad(const float* dY, const float* W, float* dX, int M, int N
     if (M == 0) return;
     const unsigned grid = (unsigned)(cdiv(M, 16) * (K / 16));
     hipLaunchKernelGGL(dense_dgrad_kernel, dim3(grid), dim3(256), 0, s, dY, W, dX, M, N, K, mask, mask_scale, mode == GEMM_BF16 ? 1 : 0);
+    CMOOP_HIP(hipGetLastError());
+}
+
+void launch_dense_bwd(const float* X, const float* dY, const float* W, float* dW, float* dB, float* dX, int M, int N, int K,
+                      const float* mask, float mask_scale, int mode, hipStream_t s) {
+    check_dense(M, N, K);
+    const unsigned wg = (unsigned)(cdiv(N, 16) * (K / 16)), dg = (unsigned)(cdiv(M, 16) * (K / 16));
+    hipLaunchKernelGGL(dense_bwd_kernel, dim3(wg + dg), dim3(256), 0, s, X, dY, W, dW, dB, dX, M, N, K, mask, mask_scale,
+                       mode == GEMM_BF16 ? 1 : 0, (int)wg);
     CMOOP_HIP(hipGetLastError());
 }
 

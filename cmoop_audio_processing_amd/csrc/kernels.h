@@ -128,6 +128,9 @@ void launch_dense_dgrad(const float* dY, const float* W, float* dX, int M, int N
                         int mode, hipStream_t s);
 // dW[n][k] = sum_m dY[m][n] X[m][k], dB[n] = sum_m dY[m][n]
 void launch_dense_wgrad(const float* X, const float* dY, float* dW, float* dB, int M, int N, int K, int mode, hipStream_t s);
+// both of the above in one launch (same arithmetic, bit-identical results): the trainer's backward of a hidden dense layer
+void launch_dense_bwd(const float* X, const float* dY, const float* W, float* dW, float* dB, float* dX, int M, int N, int K,
+                      const float* mask, float mask_scale, int mode, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // First layer (C_in = 1, K = 9 or 25: too small for MFMA) -- direct conv on the VALU.

@@ -686,6 +686,14 @@ void Net::backward(const float* X, const int32_t* idx, int64_t row0, int B, cons
         case OP_DENSE: {
             const float* dY = acts_[op.out].grad;
             Act& ia = acts_[op.in];
+            // CMOOP_DENSE_UNFUSED=1 (read per step, like CMOOP_ADAM_UNFUSED): the two launches of round 2 instead of the merged one
+            const char* du = std::getenv("CMOOP_DENSE_UNFUSED");
+            const bool unfused = du && du[0] == '1';
+            if (op.need_dgrad && !unfused) {
+                launch_dense_bwd(ia.data, dY, params_ + op.w_off, grads_ + op.w_off, grads_ + op.b_off, ia.grad, B, op.Cout, op.Cin,
+                                 op.in_is_relu ? ia.data : nullptr, op.in_mask_scale, op.gemm_mode, stream_);
+                break;
+            }
             launch_dense_wgrad(ia.data, dY, grads_ + op.w_off, grads_ + op.b_off, B, op.Cout, op.Cin, op.gemm_mode, stream_);
             if (op.need_dgrad)
                 launch_dense_dgrad(dY, params_ + op.w_off, ia.grad, B, op.Cout, op.Cin, op.in_is_relu ? ia.data : nullptr,

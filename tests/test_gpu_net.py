@@ -635,6 +635,29 @@ def test_optimiser_launch_sums_the_weight_gradient_slabs_bit_exactly(monkeypatch
 
 
 
+def test_merged_dense_backward_launch_equals_the_two_launches_bit_for_bit(monkeypatch):
+    """r3: the weight gradient and the data gradient of a hidden dense layer share ONE launch (dense_bwd_kernel: the same two
+    bodies on disjoint workgroup ranges).  Four steps (full, partial, full, full) of a four-layer MLP head with dropout must
+    leave bit-identical parameters and gradients under the round-2 launch pair (CMOOP_DENSE_UNFUSED, read per step)."""
+    gene, classes, seed = (16, 3, 0, 1, 4, 1), 11, 13
+    cfg = EvalConfig.preset("sa_nsga_penalty", classes=classes, batch=32, eval_batch=64, seed=seed, n_slots=1)
+    X, y = make_data(128, 41, 20, classes, 6)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    got = {}
+    for mode in ("merged", "pair"):
+        if mode == "pair":
+            monkeypatch.setenv("CMOOP_DENSE_UNFUSED", "1")
+        else:
+            monkeypatch.delenv("CMOOP_DENSE_UNFUSED", raising=False)
+        with NetSession(gene, cfg, 41, 20, seed) as net:
+            for step, b in enumerate((32, 19, 32, 32)):
+                net.train_step(Xd, yd, None, row0=32 * step, B=b)
+            got[mode] = (np.array(net.get_params()), np.array(net.get_grads()))
+    monkeypatch.delenv("CMOOP_DENSE_UNFUSED", raising=False)
+    for a, b in zip(got["merged"], got["pair"]):
+        assert np.isfinite(a).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_population_40_at_baseline_feature_size_config1():
     """BASELINE configs[1] at full population and feature size: the 40 genes of random.Random(0) (the bench's
     population), 101x40 features, a few hundred clips, one epoch.  Size-independent properties for all 40 --
