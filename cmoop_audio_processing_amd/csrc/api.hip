@@ -192,6 +192,16 @@ int cmoop_conv_launch_plan(int32_t op, int32_t B, int32_t H, int32_t W, int32_t 
     });
 }
 
+int cmoop_halo_tile_check(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t* rows_bound,
+                          int32_t* rows_needed, int32_t* rows_stageable) {
+    return guard([&] {
+        CMOOP_REQUIRE(rows_bound && rows_needed && rows_stageable && B >= 1 && H >= 1 && W >= 1 && Cin >= 16 && Cout >= 1 && KS >= 1, "bad conv shape");
+        int b = 0, n = 0, c = 0;
+        halo_rows_bound_and_need(make_geom(B, H, W, Cin, Cout, KS, 1), &b, &n, &c);
+        *rows_bound = b; *rows_needed = n; *rows_stageable = c;
+    });
+}
+
 int cmoop_wgrad_slices(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t* out) {
     return guard([&] {
         CMOOP_REQUIRE(out && B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1 && KS >= 1 && stride >= 1, "bad conv shape");

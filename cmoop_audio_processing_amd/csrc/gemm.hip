@@ -1310,6 +1310,22 @@ static bool halo_geometry(const ConvGeom& cg, HaloDev* hd, size_t* lds_bytes) {
     if (lds_bytes) *lds_bytes = lds;
     return true;
 }
+
+// host-only check of the bound above (tests): halo rows the LDS image is sized for and the largest number of rows any tile of
+// this geometry really spans (the kernel's own arithmetic: virtual rows of the tile's first and last pixel); 0 / 0 when the
+// geometry is not eligible
+void halo_rows_bound_and_need(const ConvGeom& cg, int* bound, int* need, int* items_cap) {
+    HaloDev hd;
+    size_t lds = 0;
+    *bound = *need = *items_cap = 0;
+    if (!halo_geometry(cg, &hd, &lds)) return;
+    const int R = cg.KH / 2, bm = halo_bm(cg.Cout), M = cg.M(), VH = cg.H + R;
+    auto vrow = [&](int m) { const int b = m / (cg.H * cg.W), r = m - b * cg.H * cg.W; return b * VH + r / cg.W; };
+    int worst = 0;
+    for (int m0 = 0; m0 < M; m0 += bm) worst = std::max(worst, vrow(std::min(m0 + bm, M) - 1) - vrow(m0) + 1 + 2 * R);
+    *bound = hd.rows_max; *need = worst; *items_cap = halo_nst(bm) * 256 / (hd.WP * 4);
+}
+
 static FwdChoice choose_fwd(const ConvGeom& cg, const GemmEpilogue& ep, size_t ws_floats, bool want_stats, bool have_rowtab) {
     FwdChoice c;
     const int M = cg.M(), N = cg.Cout, K = cg.K();

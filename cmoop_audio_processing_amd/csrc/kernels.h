@@ -68,6 +68,9 @@ size_t igemm_splitk_workspace(const ConvGeom& g);
 // geometry takes -- ws_floats: split-K workspace the caller would pass (0: none); S: wgrad row slices (wgrad_slices)
 int igemm_fwd_plan(const ConvGeom& g, const GemmEpilogue& e, size_t ws_floats, bool want_stats, bool have_rowtab, int* flags_out);
 int igemm_wgrad_plan(const ConvGeom& g, int S, int mode, bool have_rowtab, int* flags_out);
+// host-only (tests): rows the halo kernel's LDS image is sized for, the most rows any tile of this geometry spans, and the rows
+// the per-thread staging slots can hold -- need <= bound <= items_cap must hold for every eligible geometry; all 0 if not eligible
+void halo_rows_bound_and_need(const ConvGeom& g, int* bound, int* need, int* items_cap);
 // throws when a tensor of this geometry is beyond the kernels' 32-bit BYTE offsets (buffer descriptors, row tables):
 // B*H*W*Cin (+ padding bias) and M*Cout must stay below 2^29 elements
 void igemm_check_range(const ConvGeom& g);

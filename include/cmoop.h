@@ -117,6 +117,13 @@ int cmoop_plan_check(const int32_t gene[6], int32_t variant, int32_t T, int32_t 
 int cmoop_conv_launch_plan(int32_t op, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride,
                            int32_t want_stats, char* name, int32_t name_cap);
 
+/* host-only: the halo-tiled direct convolution (stride-1 KS x KS layers) stages the input rows of a 128- / 256-pixel tile in LDS;
+ * rows_bound = rows its LDS image is sized for (closed form), rows_needed = the most rows any tile of this geometry really
+ * spans, rows_stageable = rows the per-thread staging slots can hold.  All 0 when the geometry runs on the implicit GEMM.
+ * Tests sweep geometries and require rows_needed <= rows_bound <= rows_stageable. */
+int cmoop_halo_tile_check(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t* rows_bound,
+                          int32_t* rows_needed, int32_t* rows_stageable);
+
 /* host-only: number of row slices the weight-gradient kernel splits a conv/dense layer into (workspace sizing;
  * NOT monotone in B -- tests pin that the trainer sizes its slab workspace for the worst batch 1..cfg.batch) */
 int cmoop_wgrad_slices(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t* out);

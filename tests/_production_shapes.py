@@ -42,6 +42,8 @@ PRODUCTION_CONVS = [
     (256, 13, 5, 256, 512, 3, 1),
     (64, 51, 20, 16, 32, 5, 1),      # 256 x 32 halo tile, one 16-channel chunk
     (64, 51, 20, 32, 32, 3, 1),
+    (64, 32, 32, 32, 64, 3, 1),      # BASELINE configs[3] (BirdCLEF-shaped 128x128 patches) after two / three pools: other row widths
+    (64, 16, 16, 64, 128, 5, 1),     # (W = 32: halo pitch 40; W = 16, k5: pitch 24, tiles of 8 image rows)
     (51, 51, 20, 32, 64, 3, 1),      # the partial batch of tests/test_gpu_net.py::test_wgrad_workspace_partial_batches_advice_r1
     (51, 51, 20, 64, 64, 3, 1),      # (ragged row slices of the halo weight gradient)
     # the skip projections at the inference batch: many-wave grids of the implicit GEMM's 128-row tiles

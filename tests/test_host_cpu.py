@@ -311,6 +311,32 @@ def test_every_launch_variant_of_every_gene_has_a_gpu_parity_case():
     assert {"halo_fwd_kernel<5, 128, 64, 2, false>+stats", "halo_fwd_kernel<3, 256, 32, 4, false>", "halo_fwd_kernel<5, 128, 64, 2, true>+bal", "halo_wgrad_kernel<5, 10>+slabs", "halo_wgrad_kernel<3, 5>+slabs"} <= covered
 
 
+def test_halo_tile_bound_covers_every_tile_of_every_geometry():
+    """The halo-tiled direct convolution sizes its LDS image and its per-thread staging slots from a closed-form bound on the
+    rows a flat 128- / 256-pixel tile can span (image boundaries add gap rows).  cmoop_halo_tile_check walks every tile of
+    a geometry with the kernel's own row arithmetic: the bound must cover the worst tile and fit the staging slots -- for
+    the search space's layer sizes, the BirdCLEF-shaped ones, odd widths and batches that put 1 ... 3 images into a tile."""
+    L = _lib.lib()
+    eligible = 0
+    for (H, W) in [(101, 40), (51, 20), (26, 10), (13, 5), (7, 3), (32, 32), (16, 16), (8, 8), (41, 20), (21, 12), (11, 6), (6, 3),
+                   (3, 40), (2, 2), (1, 40), (5, 1), (64, 64), (128, 128), (9, 17), (100, 7)]:
+        for B in (1, 2, 37, 64, 256):
+            for (Cin, Cout) in ((16, 16), (32, 32), (64, 64), (128, 256)):
+                for KS in (3, 5):
+                    b, n, c = C.c_int32(), C.c_int32(), C.c_int32()
+                    _lib.check(L.cmoop_halo_tile_check(B, H, W, Cin, Cout, KS, C.byref(b), C.byref(n), C.byref(c)))
+                    if b.value:
+                        eligible += 1
+                        assert n.value <= b.value <= c.value, ((B, H, W, Cin, Cout, KS), n.value, b.value, c.value)
+    assert eligible > 300
+    # the layers of the benchmark are eligible; a 128-wide row is not (its halo does not fit the staging slots)
+    b, n, c = C.c_int32(), C.c_int32(), C.c_int32()
+    _lib.check(L.cmoop_halo_tile_check(64, 101, 40, 64, 64, 5, C.byref(b), C.byref(n), C.byref(c)))
+    assert (b.value, n.value) == (11, 10)           # the closed form is one row conservative here
+    _lib.check(L.cmoop_halo_tile_check(64, 128, 128, 64, 64, 5, C.byref(b), C.byref(n), C.byref(c)))
+    assert b.value == 0
+
+
 def test_32bit_byte_offset_guard_refuses_oversized_plans():
     """ADVICE r2 / VERDICT r2 item 9: buffer descriptors, row tables and per-row offsets hold BYTES in 32 bits, so every
     tensor a GEMM launch addresses must stay below 2^29 elements; beyond that the hardware range check would return
