@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <type_traits>
 
 namespace cmoop {
 
@@ -822,6 +823,8 @@ __global__ __launch_bounds__(256, 2) void halo_fwd_kernel(const float* __restric
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(X), 0, (int)((uint32_t)g.B * g.H * g.W << g.cshift) * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, g.Cout * g.K * 4, 0x00020000);
+    // (Measured, not adopted: the image / row decode of the staging slots through a per-row table in LDS -- 313 instead of 367 vector
+    // instructions in the tile prologue -- no measurable change on any shape.)
     uint32_t s_voff[NST];
 #pragma unroll
     for (int it = 0; it < NST; ++it) {
@@ -1006,6 +1009,59 @@ __global__ __launch_bounds__(256, 2) void halo_fwd_kernel(const float* __restric
         const int col = n0 + wcol + ct * 16 + lr;
         bias_v[ct] = (e.bias && col < N) ? e.bias[col] : 0.f;
     }
+    // Two straight-line forms for whole tiles -- the forward launch (bias, ReLU, statistics) and the dgrad launch (ReLU-backward
+    // mask, residual accumulate) -- and the general form below for ragged last tiles and everything else.  A per-tile epilogue
+    // instruction takes issue time from the co-resident workgroups' MFMAs like any other: the general form spends ~15 vector /
+    // scalar instructions per element on guards, option branches and 64-bit addresses and waits for each mask load separately;
+    // the straight-line forms address with one per-lane byte offset + a scalar row term + an immediate column term (buffer
+    // instructions), batch a 16-row group's loads, and carry no per-element branch.  Same arithmetic in the same order.
+    const bool whole = m0 + BM <= g.M && (N % BN) == 0;
+    const uint32_t e_lane = (uint32_t)((m0 + wrow + q * 4) * N + n0 + wcol + lr) * 4u;     // element (rt 0, r 0, ct 0) of this lane, bytes
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, g.M * N * 4, 0x00020000);
+    if (whole && !e.dropout && !e.mask && !e.accumulate) {
+        auto store_all = [&](auto relu_c, auto stats_c) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int soff = (rt * 16 + r) * N * 4;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        float v = acc[rt][ct][r] + bias_v[ct];
+                        if constexpr (decltype(relu_c)::value) v = fmaxf(v, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)(e_lane + ct * 64), soff, 0);
+                        if constexpr (decltype(stats_c)::value) { csum[ct] += v; csq[ct] += v * v; }
+                    }
+                }
+        };
+        using T1 = std::integral_constant<bool, true>;
+        using T0 = std::integral_constant<bool, false>;
+        if (e.relu) { if (e.stats) store_all(T1{}, T1{}); else store_all(T1{}, T0{}); }
+        else        { if (e.stats) store_all(T0{}, T1{}); else store_all(T0{}, T0{}); }
+    } else if (whole && e.mask && !e.dropout && !e.relu && !e.bias && !e.stats) {
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.mask), 0, g.M * N * 4, 0x00020000);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float mk[4][CT], old[4][CT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int soff = (rt * 16 + r) * N * 4;
+                    mk[r][ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrs, (int)(e_lane + ct * 64), soff, 0));
+                    old[r][ct] = e.accumulate ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, (int)(e_lane + ct * 64), soff, 0)) : 0.f;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int soff = (rt * 16 + r) * N * 4;
+                    float v = (mk[r][ct] > 0.f) ? acc[rt][ct][r] * e.mask_scale : 0.f;
+                    if (e.accumulate) v += old[r][ct];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)(e_lane + ct * 64), soff, 0);
+                }
+        }
+    } else {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -1031,6 +1087,7 @@ __global__ __launch_bounds__(256, 2) void halo_fwd_kernel(const float* __restric
                 csq[ct] += v * v;
             }
         }
+    }
     }
     if (e.stats) {
         __syncthreads();                       // the halo image is dead: reuse it for the cross-wave column sums
@@ -1357,14 +1414,16 @@ static FwdChoice choose_fwd(const ConvGeom& cg, const GemmEpilogue& ep, size_t w
     // the implicit GEMM everywhere).  Isolated forward / dgrad TFLOP/s, halo vs implicit GEMM (profiles/r03_halo_kernel_bench.txt):
     // 64->64 k5 @101x40 137.5 vs 122.1, k3 113 / 122 vs 105 / 114; 64->64 k5 @51x20 132.6 vs 117; 128->64 k5 (dgrad of 64->128)
     // 139.2 vs 122.9; 32->32 k5 @101x40 119.4 vs 110 (LDS-DMA tile), @51x20 107 vs 93; 16->16 k5 90.4 vs 66.7, k3 51 vs 46.
-    // The one shape it loses is 32->32 k3 @101x40 (78.7 vs 87.2: two halo refills of a 256-pixel tile per 576 MFMAs), excluded below.
+    // (32->32 k3 @101x40 lost at first -- 78.7 vs 87.2 on the LDS-DMA tile -- and was excluded until the straight-line epilogue: 96.6 / 99.2 now.)
+    // With the straight-line epilogue forms (see the kernel): 64->64 k5 @101x40 143 / 144, k3 133 / 133, 128->128 k5 @51x20 144 / 145,
+    // 32->32 k5 129, 16->16 k5 104, 16->16 k3 68; the pop-40 job 2 337 vs 2 289-2 297 evals/h.
     // 128-column layers run as two 64-column workgroups per tile: alone the second round of workgroups has a ragged tail
     // (128->128 k5 @51x20: 117 vs 130; a 128 x 128 halo tile did 136), in the job it is the better form (2 225 vs 2 195 vs
     // 2 180 evals/h for 64-column halo / 128-column halo / implicit GEMM).
     static const bool halo_env = [] { const char* v = std::getenv("CMOOP_HALO"); return !(v && v[0] == '0'); }();
     c.ks = cg.KH;
     c.halo = halo_env && (c.mode == GEMM_FP32 || c.mode == GEMM_FP32_DMA) && c.bm == 128 && c.splits == 1 && !c.balanced_wgs && ep.out_stride == 1 &&
-             halo_geometry(cg, nullptr, nullptr) && !(cg.Cout == 32 && cg.KH == 3 && cg.W > 20);
+             halo_geometry(cg, nullptr, nullptr);
     c.halo_L = 0;
     if (c.halo) {
         c.mode = GEMM_FP32_HALO; c.use_dma = false;

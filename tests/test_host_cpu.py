@@ -306,7 +306,7 @@ def test_every_launch_variant_of_every_gene_has_a_gpu_parity_case():
         assert not missing, f"launch-path variants without a GPU parity case (topology {variant}): {missing}"
     assert len(covered) >= 30
     # the names are the ones rocprofv3 prints: the LDS-DMA instantiation carries MODE = 1
-    assert "igemm_fwd_kernel<128, 32, 32, 4, 1>+stats+tab" in covered and "igemm_wgrad_kernel<128, 128, 32>+tab+slabs" in covered and "igemm_wgrad_kernel<64, 64, 64>+tab+slabs" in covered
+    assert "igemm_fwd_kernel<128, 32, 32, 4, 1>+tab" in covered and "igemm_wgrad_kernel<128, 128, 32>+tab+slabs" in covered and "igemm_wgrad_kernel<64, 64, 64>+tab+slabs" in covered
     # round 3: the halo-tiled direct convolution and weight gradient of the stride-1 layers with many output pixels
     assert {"halo_fwd_kernel<5, 128, 64, 2, false>+stats", "halo_fwd_kernel<3, 256, 32, 4, false>", "halo_fwd_kernel<5, 128, 64, 2, true>+bal", "halo_wgrad_kernel<5, 10>+slabs", "halo_wgrad_kernel<3, 5>+slabs"} <= covered
 

@@ -1,3 +1,4 @@
-bash tools/gpu_steps.sh h16 \
- "200 CMOOP_HALO_DBG=2 python tools/kernel_bench.py '64,64,'" \
- "200 CMOOP_HALO_DBG=3 python tools/kernel_bench.py '64,64,'"
+bash tools/gpu_steps.sh h23 \
+ "200 python tools/kernel_bench.py '32,32,3'" \
+ "200 CMOOP_HALO_K3_32=1 python tools/kernel_bench.py '32,32,3'" \
+ "400 bash tools/ab_bench.sh h23ab - CMOOP_HALO_K3_32=1"
