@@ -666,6 +666,55 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         const int col = n0 + wcol + ct * 16 + lr;
         bias_v[ct] = (e.bias && col < N) ? e.bias[col] : 0.f;    // once per column, not once per stored element
     }
+    // straight-line forms for whole tiles of dense-stored outputs (see halo_fwd_kernel's epilogue): the short-K launches left to this
+    // kernel -- the 1x1 skip projections, the small candidates' deep layers -- are mostly epilogue
+    const bool whole = m0 + BM <= g.M && (N % BN) == 0 && e.out_stride == 1;
+    const uint32_t e_lane = (uint32_t)((m0 + wrow + q * 4) * N + n0 + wcol + lr) * 4u;     // element (rt 0, r 0, ct 0) of this lane, bytes
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, g.M * N * 4, 0x00020000);
+    if (whole && !e.dropout && !e.mask && !e.accumulate) {
+        auto store_all = [&](auto relu_c, auto stats_c) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int soff = (rt * 16 + r) * N * 4;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        float v = acc[rt][ct][r] + bias_v[ct];
+                        if constexpr (decltype(relu_c)::value) v = fmaxf(v, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)(e_lane + ct * 64), soff, 0);
+                        if constexpr (decltype(stats_c)::value) { csum[ct] += v; csq[ct] += v * v; }
+                    }
+                }
+        };
+        using T1 = std::integral_constant<bool, true>;
+        using T0 = std::integral_constant<bool, false>;
+        if (e.relu) { if (e.stats) store_all(T1{}, T1{}); else store_all(T1{}, T0{}); }
+        else        { if (e.stats) store_all(T0{}, T1{}); else store_all(T0{}, T0{}); }
+    } else if (whole && e.mask && !e.dropout && !e.relu && !e.bias && !e.stats) {
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.mask), 0, g.M * N * 4, 0x00020000);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float mk[4][CT], old[4][CT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int soff = (rt * 16 + r) * N * 4;
+                    mk[r][ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrs, (int)(e_lane + ct * 64), soff, 0));
+                    old[r][ct] = e.accumulate ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, (int)(e_lane + ct * 64), soff, 0)) : 0.f;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int soff = (rt * 16 + r) * N * 4;
+                    float v = (mk[r][ct] > 0.f) ? acc[rt][ct][r] * e.mask_scale : 0.f;
+                    if (e.accumulate) v += old[r][ct];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)(e_lane + ct * 64), soff, 0);
+                }
+        }
+    } else {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -698,6 +747,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
                 csq[ct] += v * v;
             }
         }
+    }
     }
     if (e.stats) {
         // BatchNorm batch statistics ride along: column sums over this tile's rows in a fixed order (lane's rows ->

@@ -1,4 +1,4 @@
-bash tools/gpu_steps.sh h23 \
- "200 python tools/kernel_bench.py '32,32,3'" \
- "200 CMOOP_HALO_K3_32=1 python tools/kernel_bench.py '32,32,3'" \
- "400 bash tools/ab_bench.sh h23ab - CMOOP_HALO_K3_32=1"
+bash tools/gpu_steps.sh h24 \
+ "900 python -m pytest tests -x -q -m gpu" \
+ "300 bash tools/ab_bench.sh h24ab -" \
+ "200 python bench.py --lone-only --lone-steps 40 --lone-gene 16,3,1,1,1,1 > gpurun_out/h24/lone_small.json 2>/dev/null"
