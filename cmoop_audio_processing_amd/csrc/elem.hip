@@ -4,6 +4,8 @@
 // NHWC tensors (coalesced 16 B/lane); every cross-thread sum has a fixed order so
 // a training run is bit-reproducible.
 #include "kernels.h"
+#include <cstdlib>
+#include <algorithm>
 
 namespace cmoop {
 
@@ -80,9 +82,188 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same layer on the matrix core [r3]: out[pixel][co] = sum_tap x[pixel + tap] W[co][tap] is a GEMM with K = KS*KS (9 / 25,
+// padded to 12 / 28 with zero weights).  It is not the 0.8 GFLOP that matter -- the layer is bound by its 66 MB output -- but the
+// 400 FMAs per thread of the VALU form above execute on the SIMDs the other candidates' MFMA kernels are issuing on.  Here a
+// workgroup stages the single-channel input halo of 256 consecutive output pixels (a few KB; rows of the virtual tall image as
+// in halo_fwd_kernel, the shuffle gather resolved once per halo ROW), every lane reads its K values straight from that image
+// (one ds_read_b32 per MFMA operand), the weights sit in registers, and the epilogue is the straight-line one of the halo
+// kernel with the BatchNorm statistics partials riding along (no stand-alone statistics pass after the first layer).
+// ---------------------------------------------------------------------------
+struct Conv1Dev {
+    int B, H, W, Cout, M, WP, VH, rows_max;
+    uint32_t hw_magic, hw_shift, w_magic, w_shift, wp_magic, wp_shift, vh_magic, vh_shift;
+};
+static void c1_fastdiv_init(int d, uint32_t* magic, uint32_t* shift) {     // Granlund-Montgomery, exact for n < 2^31 (as in gemm.hip)
+    uint32_t sh = 0;
+    while ((1u << sh) < (uint32_t)d) ++sh;
+    *shift = sh;
+    *magic = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - (uint64_t)d)) / (uint64_t)d + 1);
+}
+__device__ __forceinline__ int c1_fastdiv(int n, uint32_t magic, uint32_t shift) {
+    return (int)((__umulhi((uint32_t)n, magic) + (uint32_t)n) >> shift);
+}
+
+template <int KS, int CT>   // CT = Cout / 16
+__global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __restrict__ X, const int32_t* __restrict__ idx, int64_t row0,
+                                                             const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                             float* __restrict__ Y, Conv1Dev g, int relu,
+                                                             const StepState* __restrict__ st, int64_t n_rows,
+                                                             float* __restrict__ stats) {
+    constexpr int R = KS / 2, T = KS * KS, NJ = (T + 3) / 4, BM = 256, RT = 4, NIT = 4;
+    extern __shared__ __attribute__((aligned(16))) float c1_lds[];
+    float* const img = c1_lds;                                                   // [rows_max][WP]
+    long long* const row_src = reinterpret_cast<long long*>(c1_lds + g.rows_max * g.WP);   // element offset of each halo row's x = 0, or -1
+    if (st) row0 = st->row0;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * BM, N = g.Cout;
+    auto vrow = [&](int m, int& x) {
+        const int b = c1_fastdiv(m, g.hw_magic, g.hw_shift), r = m - b * (g.H * g.W);
+        const int y = c1_fastdiv(r, g.w_magic, g.w_shift);
+        x = r - y * g.W;
+        return b * g.VH + y;
+    };
+    int xd;
+    const int vbase = vrow(m0, xd), vlast = vrow(min(m0 + BM, g.M) - 1, xd);
+    const int nrows = vlast - vbase + 1 + 2 * R;
+    if (t < g.rows_max) {
+        const int v = vbase - R + t, vc = max(v, 0);
+        const int b = c1_fastdiv(vc, g.vh_magic, g.vh_shift), y = vc - b * g.VH;
+        const bool ok = t < nrows && v >= 0 && b < g.B && y < g.H;
+        row_src[t] = ok ? gather_row(idx, row0 + b, n_rows) * (long long)(g.H * g.W) + (long long)y * g.W : -1ll;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = t + 256 * it;
+        if (i < g.rows_max * g.WP) {
+            const int hy = c1_fastdiv(i, g.wp_magic, g.wp_shift), x = i - hy * g.WP - R;
+            const long long src = row_src[hy];
+            img[i] = (src >= 0 && (unsigned)x < (unsigned)g.W) ? X[src + x] : 0.f;
+        }
+    }
+    // weights: lane (co = 16 ct + lr, k slot q) holds tap 4 j + q of its output channel for the j-th MFMA (zero past the window)
+    float bw[CT][NJ];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bw[ct][j] = (4 * j + q < T) ? Wt[(ct * 16 + lr) * T + 4 * j + q] : 0.f;
+    // this lane's tap offsets inside the halo image, and its four pixels
+    int tap_off[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int tap = min(4 * j + q, T - 1), ky = tap / KS;
+        tap_off[j] = ky * g.WP + (tap - ky * KS);
+    }
+    int a_base[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        int x;
+        const int v = vrow(min(m0 + wave * 64 + rt * 16 + lr, g.M - 1), x);
+        a_base[rt] = (v - vbase) * g.WP + x;
+    }
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float a = img[a_base[rt] + tap_off[j]];
+            if (4 * j + q >= T) a = 0.f;                   // the padded K slots: 0 x W(0) even if the image held a non-finite value
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ct][j], acc[rt][ct], 0, 0, 0);
+        }
+
+    // epilogue (C/D map of 16x16x4: col = lane & 15, row = 4 (lane >> 4) + reg); whole tiles take the straight-line form
+    float csum[CT], csq[CT], bias_v[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { csum[ct] = 0.f; csq[ct] = 0.f; bias_v[ct] = bias[ct * 16 + lr]; }
+    if (m0 + BM <= g.M) {
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, g.M * N * 4, 0x00020000);
+        const uint32_t e_lane = (uint32_t)((m0 + wave * 64 + q * 4) * N + lr) * 4u;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int soff = (rt * 16 + r) * N * 4;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    float v = acc[rt][ct][r] + bias_v[ct];
+                    v = relu ? fmaxf(v, 0.f) : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)(e_lane + ct * 64), soff, 0);
+                    csum[ct] += v; csq[ct] += v * v;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wave * 64 + rt * 16 + q * 4 + r;
+                if (row >= g.M) continue;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    float v = acc[rt][ct][r] + bias_v[ct];
+                    v = relu ? fmaxf(v, 0.f) : v;
+                    Y[(size_t)row * N + ct * 16 + lr] = v;
+                    csum[ct] += v; csq[ct] += v * v;
+                }
+            }
+    }
+    if (stats) {   // column partials of this tile: lane's rows -> the wave's four row groups (shuffle) -> the four waves (LDS), fixed order
+        __syncthreads();
+        float* red = c1_lds;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            csum[ct] += __shfl_xor(csum[ct], 16, 64); csq[ct] += __shfl_xor(csq[ct], 16, 64);
+            csum[ct] += __shfl_xor(csum[ct], 32, 64); csq[ct] += __shfl_xor(csq[ct], 32, 64);
+            if (q == 0) { red[(wave * N + ct * 16 + lr) * 2] = csum[ct]; red[(wave * N + ct * 16 + lr) * 2 + 1] = csq[ct]; }
+        }
+        __syncthreads();
+        if (t < N) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[(w * N + t) * 2]; b += red[(w * N + t) * 2 + 1]; }
+            stats[((size_t)blockIdx.x * 2) * N + t] = a;
+            stats[((size_t)blockIdx.x * 2 + 1) * N + t] = b;
+        }
+    }
+}
+
 void launch_conv1_fwd(const float* X, const int32_t* idx, int64_t row0, const float* Wt, const float* bias, float* Y,
-                      int B, int H, int W, int Cout, int KS, int relu, hipStream_t s, const StepState* st, int64_t n_rows) {
+                      int B, int H, int W, int Cout, int KS, int relu, hipStream_t s, const StepState* st, int64_t n_rows,
+                      float* stats, int* stats_blocks) {
     CMOOP_REQUIRE(Cout % 4 == 0 && Cout <= 64 && 64 % (Cout / 4) == 0 && (KS == 3 || KS == 5), "conv1: unsupported shape");
+    if (stats_blocks) *stats_blocks = 0;
+    // matrix-core form (default; CMOOP_CONV1_MFMA=0 keeps the VALU kernel): C_out a multiple of 16, halo image within the staging slots
+    static const bool mfma_on = [] { const char* v = std::getenv("CMOOP_CONV1_MFMA"); return !(v && v[0] == '0'); }();
+    {
+        const int R = KS / 2, wp = (W + KS - 1 + 7) / 8 * 8;
+        const int span = (256 - 2 + W) / W + 1 + ((256 - 1) / (H * W) + 1) * R, rows = span + 2 * R;
+        const int64_t M = (int64_t)B * H * W;
+        if (mfma_on && (Cout == 16 || Cout == 32 || Cout == 64) && rows * wp <= 4 * 256 && rows <= 256 && M > 0 && M * Cout < (1ll << 29)) {
+            Conv1Dev g;
+            g.B = B; g.H = H; g.W = W; g.Cout = Cout; g.M = (int)M; g.WP = wp; g.VH = H + R; g.rows_max = rows;
+            c1_fastdiv_init(H * W, &g.hw_magic, &g.hw_shift);
+            c1_fastdiv_init(W, &g.w_magic, &g.w_shift);
+            c1_fastdiv_init(wp, &g.wp_magic, &g.wp_shift);
+            c1_fastdiv_init(H + R, &g.vh_magic, &g.vh_shift);
+            const size_t lds = std::max((size_t)rows * wp * 4 + (size_t)rows * 8, (size_t)4 * Cout * 2 * 4);
+            const dim3 grid((unsigned)cdiv64(M, 256));
+#define CMOOP_C1(KS_, CT_) hipLaunchKernelGGL((conv1_fwd_mfma_kernel<KS_, CT_>), grid, dim3(256), lds, s, X, idx, row0, Wt, bias, Y, g, relu, st, n_rows, stats)
+            if (KS == 3) { if (Cout == 16) CMOOP_C1(3, 1); else if (Cout == 32) CMOOP_C1(3, 2); else CMOOP_C1(3, 4); }
+            else         { if (Cout == 16) CMOOP_C1(5, 1); else if (Cout == 32) CMOOP_C1(5, 2); else CMOOP_C1(5, 4); }
+#undef CMOOP_C1
+            CMOOP_HIP(hipGetLastError());
+            if (stats && stats_blocks) *stats_blocks = (int)grid.x;
+            return;
+        }
+    }
     const int GPB = 256 / (Cout / 4);
     const int64_t groups = (int64_t)B * H * ((W + 3) / 4);
     if (groups == 0) return;

@@ -143,9 +143,11 @@ void launch_dense_bwd(const float* X, const float* dY, const float* W, float* dW
 // st (optional): the batch's first row comes from st->row0 instead of row0
 // n_rows (optional, > 0): rows the resident tensor holds -- a gathered row index is clamped into [0, n_rows) so that a
 // corrupt idx can never address outside X (the only producer of idx is the device permutation; this is a fault fence)
+// stats / stats_blocks (optional): column partials (sum, sum of squares) of the stored output, [blocks][2][Cout] -- written by the
+// matrix-core form only (*stats_blocks = 0 otherwise: the caller then runs the stand-alone reduction)
 void launch_conv1_fwd(const float* X, const int32_t* idx, int64_t row0, const float* Wt, const float* bias,
                       float* Y, int B, int H, int W, int Cout, int KS, int relu, hipStream_t s, const StepState* st = nullptr,
-                      int64_t n_rows = 0);
+                      int64_t n_rows = 0, float* stats = nullptr, int* stats_blocks = nullptr);
 int conv1_wgrad_blocks(int B, int H, int W);
 // P[blk][Cout*(KS*KS) + Cout]: per-block partial kernel grads then bias grads
 void launch_conv1_wgrad(const float* X, const int32_t* idx, int64_t row0, const float* dY, float* P,

@@ -220,7 +220,7 @@ void Net::build_plan() {
         return op.out;
     };
     auto add_bn = [&](int in, int relu_after, int mask_in_pos) {
-        if (!ops_.empty() && ops_.back().kind == OP_CONV && ops_.back().out == in) ops_.back().feeds_bn = 1;
+        if (!ops_.empty() && (ops_.back().kind == OP_CONV || ops_.back().kind == OP_CONV1) && ops_.back().out == in) ops_.back().feeds_bn = 1;
         Op op; op.kind = OP_BN; op.in = in; op.relu_after = relu_after; op.mask_in_pos = mask_in_pos;
         const Act ia = acts_[in];
         op.Cout = ia.C;
@@ -607,8 +607,10 @@ void Net::forward(const float* X, const int32_t* idx, int64_t row0, int B, bool 
         const Op& op = ops_[oi];
         switch (op.kind) {
         case OP_CONV1:
+            fused_stats_blocks_ = 0;
             launch_conv1_fwd(X, idx, row0, params_ + op.w_off, params_ + op.b_off, acts_[op.out].data, B, T_, F_, op.Cout,
-                             op.KS, op.relu, stream_, st, train ? gather_rows_ : 0);
+                             op.KS, op.relu, stream_, st, train ? gather_rows_ : 0, (train && op.feeds_bn) ? red_ws_ : nullptr,
+                             (train && op.feeds_bn) ? &fused_stats_blocks_ : nullptr);
             break;
         case OP_CONV: {
             GemmEpilogue e;

@@ -63,6 +63,14 @@ CONV_CASES = [
     (2, 21, 12, 1, 16, 3, 1, 1),       # first layer (C_in = 1), direct kernel
     (2, 21, 12, 1, 64, 5, 1, 0),
     (1, 101, 40, 1, 32, 5, 1, 1),
+    # [r3] the first layer on the matrix core (conv1_fwd_mfma_kernel): 256-pixel tiles over the virtual tall image
+    (64, 101, 40, 1, 64, 5, 1, 1),     # the bench's shape: 1 010 whole tiles
+    (64, 101, 40, 1, 16, 3, 1, 0),
+    (37, 101, 40, 1, 32, 5, 1, 1),     # a ragged last tile
+    (3, 13, 5, 1, 64, 3, 1, 0),        # one tile over three whole images
+    (9, 7, 3, 1, 16, 5, 1, 1),         # images smaller than the window reach
+    (40, 26, 10, 1, 32, 5, 1, 0),
+    (2, 21, 12, 1, 8, 3, 1, 0),        # C_out outside the search space: the VALU form
 ]
 
 
