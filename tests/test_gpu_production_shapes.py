@@ -110,6 +110,19 @@ def test_production_conv_shapes_through_the_trainer_launch_path(B, H, W, Cin, Co
 
 
 @fp32_only
+def test_production_conv_shapes_with_the_round3_kernels_switched_off():
+    """The halo kernels and the matrix-core first layer have switches (CMOOP_HALO / CMOOP_HALO_WGRAD / CMOOP_HALO_BAL = 0): with them
+    off every layer falls back to the implicit-GEMM instantiations of mid-round 3.  The same production shapes through the same
+    trainer launch path at the same tolerances, in a child process (the switches are read once per process)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CMOOP_HALO="0", CMOOP_HALO_WGRAD="0", CMOOP_HALO_BAL="0", CMOOP_CONV1_MFMA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "production_conv_shapes_through"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and f"{len(PRODUCTION_CONVS)} passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@fp32_only
 def test_production_conv_shapes_under_the_fp32_accurate_bf16x3_mode():
     """The opt-in bf16x3 matrix-core mode (every fp32 operand split exactly into three bf16 values, six bf16 MFMA terms:
     fp32-accurate, not bit-exact) through the same production shapes and the same trainer launch path, at the exact
